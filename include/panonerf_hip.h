@@ -1,0 +1,212 @@
+/*
+ * panonerf_hip.h — C ABI of libpanonerf_hip.so (gfx950 / MI355X).
+ *
+ * The reference (Lu-Zhan/Pano-NeRF) has no FFI: its hot path is ATen op chains
+ * inside Python functions.  Each entry point below replaces one such chain; the
+ * reference file:line it stands in for is cited per function.  The Python module
+ * pano_nerf_amd binds these through ctypes (see INTEGRATION.md for the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32, row-major, contiguous, unless the
+ *     parameter name ends in _host; the caller owns all memory, the library keeps
+ *     no global state and allocates nothing;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the
+ *     call returns without synchronising (graph-capturable);
+ *   - return value: 0 on success, negative PN_ERR_* otherwise (the Python shim
+ *     raises RuntimeError(pn_strerror(code)));
+ *   - B rays, N samples per ray, S = N + 1 fence posts, M = B*N sample rows.
+ *     Sample-row buffers written by the GEMM kernels must be allocated with
+ *     pn_pad_rows(M) rows.
+ */
+#ifndef PANONERF_HIP_H
+#define PANONERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_OK 0
+#define PN_ERR_BAD_SHAPE (-1)   /* a size is <= 0 or violates a documented bound   */
+#define PN_ERR_UNSUPPORTED (-2) /* e.g. N > PN_MAX_SAMPLES, density channels not 1/5 */
+#define PN_ERR_NULL (-3)        /* a required pointer is null                       */
+#define PN_ERR_HIP (-4)         /* a HIP launch failed (hipGetLastError != success) */
+
+#define PN_MAX_SAMPLES 512 /* fence posts per ray handled by one wave: S <= 513 */
+#define PN_ENC_DIM 96      /* 2 * 3 * (max_deg_point - min_deg_point), degrees 0..15 */
+#define PN_VIEW_DIM 27     /* 3 + 2 * 3 * deg_view, deg_view = 4 */
+#define PN_WIDTH 256
+#define PN_WIDTH_COND 128
+#define PN_ROW_PAD 128
+
+const char* pn_strerror(int code);
+int pn_abi_version(void);
+/* rows a [M, *] sample buffer must be allocated with (M rounded up to PN_ROW_PAD) */
+int64_t pn_pad_rows(int64_t m);
+
+/* ---- flat parameter block --------------------------------------------------------
+ * The 24 tensors of MLP / PureMLP (models/pano_mip_nerf.py:35-76, models/mip_nerf.py:19-60)
+ * live in ONE fp32 block so that gradient all-reduce and Adam are one pass each.
+ * Order: layers.0..7 {weight,bias}, extra_layer {w,b}, view_layers.0.0 {w,b},
+ * density_layer.weight, color_layer.weight, density_layer.bias, color_layer.bias.
+ * pn_param_layout fills offsets[24] (in floats, same order as above) and returns the
+ * total float count (613768 for nc = 5, 612740 for nc = 1), or a negative error. */
+int64_t pn_param_layout(int num_density_channels, int64_t* offsets_host);
+
+/* workspace (floats) pn_pack_weights needs: transposed / split copies of the weights */
+int64_t pn_wpack_floats(int num_density_channels);
+/* (re)build the packed weights from the flat parameter block; call after every
+ * optimizer step.  Replaces nothing upstream (ATen reads nn.Linear.weight directly). */
+int pn_pack_weights(const float* params, int num_density_channels, float* wpack, void* stream);
+
+/* ---- ray generation ----------------------------------------------------------------
+ * PanoDataset._generate_rays, datasets/pano_datasets.py:152-216 (== sample_dir_by_pano,
+ * utils/sampling.py:5-20).  One camera; outputs are [H*W, C] with C = 3,3,3,1,1,1,1,1. */
+int pn_raygen_pano(int H, int W, const float* c2w_host /*[16] row-major 4x4*/, float near_, float far_,
+                   float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
+                   float* near_out, float* far_out, float* noise_var, void* stream);
+/* PanoDataset.generate_lit_rays, datasets/pano_datasets.py:218-263 (== sample_dir_by_unifrom,
+ * utils/sampling.py:23-38): fp64 math, stored as IEEE half.  out_half: 14*D uint16 laid out as
+ * origins[D,3] directions[D,3] viewdirs[D,3] radii[D] lossmult[D] near[D] far[D] noise_var[D]. */
+int pn_lit_rays(int D, double radius, double near_, double far_, uint16_t* out_half, void* stream);
+
+/* ---- sampling ----------------------------------------------------------------------
+ * sample_along_rays (models/mip.py:113-151, disparity = False) + cast_rays (67-89) +
+ * conical_frustum_to_gaussian (36-64, stable) + lift_gaussian (8-22, diagonal).
+ * t_rand: [B,S] uniforms or null (deterministic). */
+int pn_sample_coarse(int64_t B, int N, const float* origins, const float* directions, const float* radii,
+                     const float* near_, const float* far_, const float* t_rand, float* t_out, float* mean,
+                     float* cov, void* stream);
+/* resample_along_rays (models/mip.py:304-352, stop_grad branch) + sorted_piecewise_constant_pdf
+ * (240-301) + cast_rays.  u_rand: [B,S] uniforms in [0, 1/S - eps) or null. */
+int pn_resample(int64_t B, int N, const float* t_in, const float* weights, float padding, const float* u_rand,
+                const float* origins, const float* directions, const float* radii, float* t_out, float* mean,
+                float* cov, void* stream);
+/* sample_each_points (models/mip.py:154-194) for x_surf = origins + directions * distance
+ * (models/pano_mip_nerf.py:324-334).  Light ray r = b*D + j.  env_rand: [Ne+1] uniforms or null.
+ * env_dirs/env_radii/env_near/env_far: [D,*] fp32 (fp16-rounded values up-cast by the caller). */
+int pn_sample_env(int64_t B, int D, int Ne, const float* origins, const float* directions, const float* distance,
+                  const float* env_dirs, const float* env_radii, const float* env_near, const float* env_far,
+                  const float* env_rand, float* t_out /*[B*D,Ne+1]*/, float* mean /*[B*D*Ne,3]*/,
+                  float* cov /*[B*D*Ne,3]*/, void* stream);
+
+/* ---- encodings ---------------------------------------------------------------------
+ * integrated_pos_enc (models/mip.py:394-428, diagonal) -> enc [Mpad,96] */
+int pn_ipe_encode(int64_t M, const float* mean, const float* cov, float* enc, void* stream);
+/* pos_enc (models/mip.py:431-441, min_deg 0, max_deg 4, identity prepended) -> [R,27] */
+int pn_pos_enc_view(int64_t R, const float* viewdirs, float* viewenc, void* stream);
+
+/* ---- MLP ---------------------------------------------------------------------------
+ * MLP.forward / PureMLP.forward (models/pano_mip_nerf.py:95-114, models/mip_nerf.py:81-102).
+ * Rows are samples; sample row i belongs to view row (i / rows_per_ray) % view_mod
+ * (view_mod = number of rows of viewdirs).  acts: [PN_ACT_SLOTS][Mpad,256] saved activations
+ * (h0..h7, bottleneck, view hidden [.,128 used]) — required (backward and the density
+ * gradient re-read them).  enc: [Mpad,96] (written).  viewenc: [view_rows,27] (written),
+ * viewbias: [view_rows,128] scratch. */
+#define PN_ACT_SLOTS 10
+int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, const float* params,
+                   const float* wpack, const float* mean, const float* cov, const float* viewdirs, float* enc,
+                   float* viewenc, float* viewbias, float* acts, float* raw_rgb /*[M,3]*/,
+                   float* raw_density /*[M,nc]*/, void* stream);
+
+/* d sigma / d mean per sample: what vmap(jacrev(compute_graph))[1] keeps
+ * (models/pano_mip_nerf.py:299-303, models/mip_nerf.py:261-265), computed as ONE reverse
+ * sweep seeded with softplus'(raw_density0 + bias) * density_layer.weight[0].
+ * rsweep: [8][Mpad,256] saved sweep vectors (needed by pn_mlp_backward's second-order term);
+ * scratch: [Mpad,96].  Output grad_mean [M,3] = + d sigma / d mean (caller negates). */
+int pn_density_grad(int64_t M, int num_density_channels, float density_bias, const float* params,
+                    const float* wpack, const float* mean, const float* cov, const float* acts,
+                    const float* raw_density, float* rsweep, float* scratch, float* grad_mean, void* stream);
+
+/* Backward of pn_mlp_forward (+ optionally of pn_density_grad).  Accumulates (+=) into
+ * `grads` (flat block, layout of pn_param_layout).
+ *   d_raw_rgb [M,3], d_raw_density [M,nc]: upstream gradients;
+ *   v_gradmean [M,3] or null: upstream gradient w.r.t. pn_density_grad's output (second-order
+ *     path: needs rsweep from pn_density_grad; d_raw_density[:,0] receives the
+ *     softplus'' term internally);
+ *   d_mean [M,3] or null: if non-null receives d loss / d mean (first-order, env-light path).
+ * work: scratch of pn_mlp_backward_work_floats(M, view_rows) floats. */
+int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows);
+int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, float density_bias,
+                    const float* params, const float* wpack, const float* mean, const float* cov,
+                    const float* enc, const float* viewenc, const float* acts, const float* raw_density,
+                    const float* d_raw_rgb, const float* d_raw_density, const float* rsweep,
+                    const float* v_gradmean, float* d_mean, float* grads, float* work, void* stream);
+
+/* ---- volumetric rendering ---------------------------------------------------------
+ * compute_graph activations (models/pano_mip_nerf.py:273-278) + volumetric_rendering
+ * (models/mip.py:444-483).  R rays of N samples; dirs [R or dir_mod, 3] (ray r uses
+ * dirs[r % dir_mod]).  Outputs comp_rgb [R,3], distance [R], acc [R], weights [R,N]. */
+int pn_composite_forward(int64_t R, int N, int num_density_channels, float density_bias, float rgb_padding,
+                         int white_bkgd, const float* raw_rgb, const float* raw_density, const float* t,
+                         const float* dirs, int64_t dir_mod, float* comp_rgb, float* distance, float* acc,
+                         float* weights, void* stream);
+/* adjoint: d_comp_rgb [R,3], d_distance [R] (nullable), d_weights [R,N] (nullable) ->
+ * d_raw_rgb [R*N,3] (=), d_raw_density [R*N,nc] channel 0 (=; other channels untouched). */
+int pn_composite_backward(int64_t R, int N, int num_density_channels, float density_bias, float rgb_padding,
+                          int white_bkgd, const float* raw_rgb, const float* raw_density, const float* t,
+                          const float* dirs, int64_t dir_mod, const float* d_comp_rgb, const float* d_distance,
+                          const float* d_weights, float* d_raw_rgb, float* d_raw_density, void* stream);
+
+/* ---- normals / albedo gather (models/pano_mip_nerf.py:296-317, mip_nerf.py:258-275) --
+ * grad_mean [B*N,3] = d sigma/d mean; weights [B,N]; raw_density [B*N,nc].
+ * normals_s = normalize(-grad_mean); normal = normalize(sum w^ n_s); ort_ray[b] = sum w^ relu(n_s.d)^2
+ * (caller takes the mean over B); albedo = sum w^ (sigmoid(raw[1:4])*0.77+0.03) (nc = 5 only). */
+int pn_surf_gather_forward(int64_t B, int N, int num_density_channels, const float* grad_mean,
+                           const float* weights, const float* raw_density, const float* directions,
+                           float* normal /*[B,3]*/, float* ort_ray /*[B] or null*/, float* albedo /*[B,3] or null*/,
+                           void* stream);
+/* adjoint: d_normal [B,3], d_ort_ray [B] (nullable), d_albedo [B,3] (nullable) ->
+ * d_weights [B,N] (=), v_gradmean [B*N,3] (=), d_raw_density channels 1..3 (=, nc = 5). */
+int pn_surf_gather_backward(int64_t B, int N, int num_density_channels, const float* grad_mean,
+                            const float* weights, const float* raw_density, const float* directions,
+                            const float* d_normal, const float* d_ort_ray, const float* d_albedo,
+                            float* d_weights, float* v_gradmean, float* d_raw_density, void* stream);
+
+/* ---- Lambertian surface rendering (utils/surface_rendering.py:104-126, 129-165) -------
+ * env_rgb [B,D,3], albedo/normal [B,3], env_dirs [D,3], solid_angle [D].
+ * -> surface_rgb (= diffuse) [B,3], shading [B,3]. */
+int pn_surface_forward(int64_t B, int D, const float* env_rgb, const float* albedo, const float* normal,
+                       const float* env_dirs, const float* solid_angle, float* diffuse, float* shading,
+                       void* stream);
+int pn_surface_backward(int64_t B, int D, const float* env_rgb, const float* albedo, const float* normal,
+                        const float* env_dirs, const float* solid_angle, const float* d_diffuse,
+                        const float* d_shading, float* d_env_rgb, float* d_albedo, float* d_normal, void* stream);
+/* d x_surf -> d distance: d_distance[b] (+=) sum_{rows of ray b} d_mean[row] . directions[b]
+ * (models/pano_mip_nerf.py:324; rows_per_ray = D*Ne). */
+int pn_env_origin_backward(int64_t B, int rows_per_ray, const float* d_mean, const float* directions,
+                           float* d_distance, void* stream);
+
+/* ---- tone-mapped loss (utils/surface_rendering.py:319-344, systems/panonerf_system.py:17,44-67,
+ * systems/mipnerf_system.py:24,37-45).  Per-ray partials are reduced in-kernel; `loss_terms`
+ * receives [mse_coarse, mse_fine, mse_surface, chrom, mask_sum]; d_* receive the gradients of
+ *   total = cw*mse_coarse + mse_fine + sw*mse_surface + chw*chrom     (ort term added by caller).
+ * rgb_surface / albedo may be null (terms skipped).  work: >= 8 + 8*ceil(B/256) floats. */
+int pn_tonemap_loss(int64_t B, const float* rgb_gt_hdr, const float* lossmult, const float* rgb_coarse,
+                    const float* rgb_fine, const float* rgb_surface, const float* albedo, float coarse_w,
+                    float surface_w, float chrom_w, float* loss_terms /*[8]*/, float* d_coarse, float* d_fine,
+                    float* d_surface, float* d_albedo, float* work, void* stream);
+
+/* ---- optimizer: Adam over the flat block (torch.optim.Adam defaults,
+ * systems/base_system.py:82) ; grads are scaled by grad_scale first (1/world_size after a
+ * sum all-reduce). */
+int pn_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float lr,
+                 float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* ---- building blocks exposed for tests / profiling ------------------------------------
+ * C[M,N] = epi(A[M,K] * Bt[N,K]^T) on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * flags: 1 = +bias[N], 2 = relu, 4 = gate by (gate[row,col] > 0). lda/ldb/ldc/ldg in floats. */
+int pn_gemm_nt(int64_t M, int N, int K, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
+               const float* bias, const float* gate, int ldg, int flags, void* stream);
+/* C[N1,N2] = X[M,N1]^T * Y[M,N2] (split over rows, deterministic two-pass reduction);
+ * accumulate != 0 adds into C.  work: pn_gemm_tn_work_floats(M, N1, N2) floats. */
+int64_t pn_gemm_tn_work_floats(int64_t M, int N1, int N2);
+int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* Y, int ldy, float* C, int ldc,
+               int accumulate, float* work, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANONERF_HIP_H */

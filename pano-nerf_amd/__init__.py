@@ -1,0 +1,15 @@
+"""pano_nerf_amd — MI355X-native Pano-NeRF volumetric-rendering hot path.
+
+Public surface (mirrors the reference's names):
+    PanoMipNeRF, MipNeRF          models/pano_mip_nerf.py:117, models/mip_nerf.py:105
+    Rays, rearrange_render_image  datasets/base_datasets.py:13-16, models/mip.py:530-547
+    generate_pano_rays, generate_lit_rays   datasets/pano_datasets.py:152-263
+    pano_loss, mip_loss           systems/panonerf_system.py:15-75, systems/mipnerf_system.py:22-53
+    FlatAdam, mip_lr              systems/base_system.py:82-87, utils/lr_schedule.py:51-59
+"""
+__version__ = "0.1.0"
+
+from .rays import Rays, Rays_keys, namedtuple_map, rearrange_render_image, generate_pano_rays, generate_lit_rays  # noqa
+from .render import PanoMipNeRF, MipNeRF  # noqa
+from .loss import pano_loss, mip_loss  # noqa
+from .optim import FlatAdam, mip_lr  # noqa

@@ -1,0 +1,334 @@
+// pn_gemm.hip — exact-fp32 MFMA GEMMs for the radiance MLP (gfx950).
+//
+//   NT : C[M,N] = epi( sum_seg A_seg[M,K] * B_seg[N,K]^T )      forward layers, data-gradient,
+//        density-gradient sweep and tangent sweep (all with the weights in [N][K] form:
+//        the transposes are pre-packed once per step by pn_pack_weights)
+//   TN : C[N1,N2] (+)= sum_rows X[r,N1] * Y[r,N2]               weight gradients, split over rows
+//
+// Both use v_mfma_f32_32x32x2_f32 (bit-exact fp32 fma chains, 64 FLOP/clk/SIMD = 157 TF chip peak).
+// Block tile 128x128, 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).
+// K is consumed in chunks of 32 staged through LDS; the next chunk's global loads are issued
+// before the current chunk's MFMAs (register prefetch).
+//
+// Operand mapping of v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and
+// B[k = l >> 5][j = l & 31].  The k index inside an instruction is only a label, so for the NT
+// form each lane reads FOUR consecutive k of its row with one ds_read_b128 (lanes 0-31: k = 8j..8j+3,
+// lanes 32-63: k = 8j+4..8j+7) and feeds them to four consecutive MFMAs.
+#include "pn_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDT (BK + 4)   // NT tiles: [128][36] floats; +4 keeps 16-B alignment and is conflict-free for b128
+#define LDX (BM + 4)   // TN tiles: [32][132] floats
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD: give each XCD a contiguous range of tiles (bijective form).
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------- NT
+struct NtRegs {
+    f32x4 a[4], b[4];
+};
+
+__device__ __forceinline__ void nt_load(const PnGemmNt& g, int seg, int k0, int64_t m0, int n0, int tid, NtRegs& r) {
+    const PnSeg& s = g.seg[seg];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx >> 3, c4 = idx & 7;
+        int k = k0 + c4 * 4;
+        int64_t gr = m0 + row;
+        if (gr >= g.M) gr = g.M - 1;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+        if (k < s.K) va = *reinterpret_cast<const f32x4*>(s.A + gr * s.lda + k);
+        int gn = n0 + row;
+        if (k < s.K && gn < g.N) vb = *reinterpret_cast<const f32x4*>(s.B + (int64_t)gn * s.ldb + k);
+        r.a[i] = va;
+        r.b[i] = vb;
+    }
+}
+
+__device__ __forceinline__ void nt_store(float* As, float* Bs, int tid, const NtRegs& r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<f32x4*>(As + row * LDT + c4 * 4) = r.a[i];
+        *reinterpret_cast<f32x4*>(Bs + row * LDT + c4 * 4) = r.b[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nwg) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDT];
+    float* As = smem;
+    float* Bs = smem + BM * LDT;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int64_t m0 = (int64_t)(t / tiles_n) * BM;
+    const int n0 = (t % tiles_n) * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // chunk schedule over the (up to two) K segments
+    const int nc0 = (g.seg[0].K + BK - 1) / BK;
+    const int nc1 = (g.nseg > 1) ? (g.seg[1].K + BK - 1) / BK : 0;
+    const int nchunks = nc0 + nc1;
+
+    NtRegs regs;
+    nt_load(g, 0, 0, m0, n0, tid, regs);
+    nt_store(As, Bs, tid, regs);
+    __syncthreads();
+
+    const int arow = (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int brow = (wn * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = c + 1;
+        if (cn < nchunks) {
+            int seg = cn >= nc0 ? 1 : 0;
+            nt_load(g, seg, (seg ? cn - nc0 : cn) * BK, m0, n0, tid, regs);
+        }
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(As + arow + j * 8);
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(As + arow + 32 * LDT + j * 8);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + brow + j * 8);
+            f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + brow + 32 * LDT + j * 8);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (cn < nchunks) {
+            nt_store(As, Bs, tid, regs);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: acc[tm][tn][r] -> C[row][col], row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    const int flags = g.flags;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bias = (flags & PN_EPI_BIAS) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = acc[tm][tn][r] + bias;
+                if (flags & PN_EPI_ROWBIAS) {
+                    int64_t ray = row / g.rows_per_ray;
+                    if (g.rb_mod > 0) ray %= g.rb_mod;
+                    v += g.rowbias[ray * g.ldrb + col];
+                }
+                if (flags & PN_EPI_ADDC) v += g.addc[row * g.ldadd + col];
+                if (flags & PN_EPI_RELU) v = fmaxf(v, 0.f);
+                if (flags & PN_EPI_GATE) v = (g.gate[row * g.ldg + col] > 0.f) ? v : 0.f;
+                g.C[row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.nseg < 1 || g.nseg > 2) return PN_ERR_BAD_SHAPE;
+    for (int i = 0; i < g.nseg; ++i) {
+        const PnSeg& sg = g.seg[i];
+        if (sg.K <= 0 || (sg.K & 3) || (sg.lda & 3) || (sg.ldb & 3)) return PN_ERR_BAD_SHAPE;
+        if (!sg.A || !sg.B) return PN_ERR_NULL;
+        if ((reinterpret_cast<uintptr_t>(sg.A) & 15) || (reinterpret_cast<uintptr_t>(sg.B) & 15)) return PN_ERR_BAD_SHAPE;
+    }
+    if (!g.C) return PN_ERR_NULL;
+    if ((g.flags & PN_EPI_BIAS) && !g.bias) return PN_ERR_NULL;
+    if ((g.flags & PN_EPI_GATE) && !g.gate) return PN_ERR_NULL;
+    if ((g.flags & PN_EPI_ROWBIAS) && (!g.rowbias || g.rows_per_ray <= 0)) return PN_ERR_NULL;
+    if ((g.flags & PN_EPI_ADDC) && !g.addc) return PN_ERR_NULL;
+    int64_t tiles_m = (g.M + BM - 1) / BM;
+    int tiles_n = (g.N + BN - 1) / BN;
+    int64_t nwg = tiles_m * tiles_n;
+    if (nwg > 0x7fffffff) return PN_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, g, tiles_n, (int)nwg);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------- TN
+struct PnTnArgs {
+    PnSegTn seg[2];
+    int nseg;
+    int N1, N2;
+    int64_t rows_per_split;  // multiple of BK
+    int64_t chunks0;         // number of 32-row chunks of segment 0 (segment 1 follows)
+    int64_t chunks_total;
+    float* slab;             // [nsplit][N1][N2]
+};
+
+struct TnRegs {
+    f32x4 x[4], y[4];
+};
+
+__device__ __forceinline__ void tn_load(const PnTnArgs& g, int64_t chunk, int i0, int j0, int tid, TnRegs& r) {
+    int sidx = chunk >= g.chunks0 ? 1 : 0;
+    const PnSegTn& s = g.seg[sidx];
+    int64_t r0 = (sidx ? chunk - g.chunks0 : chunk) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx >> 5, c4 = idx & 31;
+        int64_t gr = r0 + row;
+        f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = {0.f, 0.f, 0.f, 0.f};
+        if (gr < s.M) {
+            int cx = i0 + c4 * 4, cy = j0 + c4 * 4;
+            if (cx < g.N1) vx = *reinterpret_cast<const f32x4*>(s.X + gr * s.ldx + cx);
+            if (cy < g.N2) vy = *reinterpret_cast<const f32x4*>(s.Y + gr * s.ldy + cy);
+        }
+        r.x[i] = vx;
+        r.y[i] = vy;
+    }
+}
+
+__device__ __forceinline__ void tn_store(float* Xs, float* Ys, int tid, const TnRegs& r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<f32x4*>(Xs + row * LDX + c4 * 4) = r.x[i];
+        *reinterpret_cast<f32x4*>(Ys + row * LDX + c4 * 4) = r.y[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDX];
+    float* Xs = smem;
+    float* Ys = smem + BK * LDX;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile = blockIdx.x;
+    const int i0 = (tile / tiles2) * BM, j0 = (tile % tiles2) * BN;
+    const int64_t split = blockIdx.y;
+    const int64_t c_begin = split * (g.rows_per_split / BK);
+    int64_t c_end = c_begin + g.rows_per_split / BK;
+    if (c_end > g.chunks_total) c_end = g.chunks_total;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (c_begin < c_end) {
+        TnRegs regs;
+        tn_load(g, c_begin, i0, j0, tid, regs);
+        tn_store(Xs, Ys, tid, regs);
+        __syncthreads();
+        const int xo = (lane >> 5) * LDX + wm * 64 + (lane & 31);
+        const int yo = (lane >> 5) * LDX + wn * 64 + (lane & 31);
+        for (int64_t c = c_begin; c < c_end; ++c) {
+            if (c + 1 < c_end) tn_load(g, c + 1, i0, j0, tid, regs);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a0 = Xs[xo + kk * 2 * LDX], a1 = Xs[xo + kk * 2 * LDX + 32];
+                float b0 = Ys[yo + kk * 2 * LDX], b1 = Ys[yo + kk * 2 * LDX + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
+            if (c + 1 < c_end) {
+                tn_store(Xs, Ys, tid, regs);
+                __syncthreads();
+            }
+        }
+    }
+    float* out = g.slab + split * (int64_t)g.N1 * g.N2;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = j0 + wn * 64 + tn * 32 + (lane & 31);
+            if (col >= g.N2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.N1) out[(int64_t)row * g.N2 + col] = acc[tm][tn][r];
+            }
+        }
+}
+
+__global__ void k_reduce_slabs(const float* slab, int nsplit, int N1, int N2, float* C, int ldc, int accumulate) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = (int64_t)N1 * N2;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * n + idx];
+    int i = (int)(idx / N2), j = (int)(idx % N2);
+    float* dst = C + (int64_t)i * ldc + j;
+    *dst = accumulate ? (*dst + s) : s;
+}
+
+static int tn_splits(int64_t Mtotal, int N1, int N2) {
+    int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
+    int64_t chunks = (Mtotal + BK - 1) / BK + 1;
+    int64_t want = (1024 + tiles - 1) / tiles;   // ~4 workgroups per CU
+    int64_t per = (chunks + want - 1) / want;    // chunks per split
+    if (per < 4) per = 4;
+    return (int)((chunks + per - 1) / per);
+}
+
+int64_t pn_tn_work_floats(int64_t Mtotal, int N1, int N2) {
+    return (int64_t)tn_splits(Mtotal, N1, N2) * N1 * N2;
+}
+
+int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, int ldc, int accumulate, float* work,
+                      hipStream_t s) {
+    if (nseg < 1 || nseg > 2 || N1 <= 0 || N2 <= 0) return PN_ERR_BAD_SHAPE;
+    if (!C || !work) return PN_ERR_NULL;
+    PnTnArgs g;
+    g.nseg = nseg;
+    int64_t Mtotal = 0;
+    for (int i = 0; i < nseg; ++i) {
+        g.seg[i] = segs[i];
+        if (segs[i].M <= 0 || (segs[i].ldx & 3) || (segs[i].ldy & 3) || !segs[i].X || !segs[i].Y) return PN_ERR_BAD_SHAPE;
+        if ((reinterpret_cast<uintptr_t>(segs[i].X) & 15) || (reinterpret_cast<uintptr_t>(segs[i].Y) & 15)) return PN_ERR_BAD_SHAPE;
+        Mtotal += segs[i].M;
+    }
+    if (nseg == 1) g.seg[1] = g.seg[0];
+    if ((N1 & 3) || (N2 & 3)) return PN_ERR_BAD_SHAPE;
+    g.N1 = N1;
+    g.N2 = N2;
+    g.chunks0 = (segs[0].M + BK - 1) / BK;
+    g.chunks_total = g.chunks0 + (nseg > 1 ? (segs[1].M + BK - 1) / BK : 0);
+    int nsplit = tn_splits(Mtotal, N1, N2);
+    int64_t per = (g.chunks_total + nsplit - 1) / nsplit;
+    g.rows_per_split = per * BK;
+    g.slab = work;
+    int tiles1 = (N1 + BM - 1) / BM, tiles2 = (N2 + BN - 1) / BN;
+    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles1 * tiles2, nsplit), dim3(256), 0, s, g, tiles2);
+    PN_CHECK_LAUNCH();
+    int64_t n = (int64_t)N1 * N2;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, work, nsplit, N1, N2, C, ldc,
+                       accumulate);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}

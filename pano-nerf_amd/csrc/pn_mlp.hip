@@ -1,0 +1,680 @@
+// pn_mlp.hip — the radiance MLP (8x256 trunk with a skip concat into layer 5, 5/1-channel density
+// head, 256->256 bottleneck, 283->128 view layer, 128->3 colour head) as chains of the exact-fp32
+// MFMA GEMMs of pn_gemm.hip, plus the narrow heads on the VALU.
+//
+//   pn_mlp_forward   : enc -> h0..h7 -> {raw_density, bottleneck -> view hidden -> raw_rgb}
+//   pn_density_grad  : ONE reverse sweep r_l = relu'(h_l) * (r_{l+1} W_{l+1}) seeded with
+//                      softplus'(z) * density_layer.weight[0]  (the reference differentiates all 8 outputs
+//                      with vmap(jacrev) and keeps one row)
+//   pn_mlp_backward  : data + weight gradients; with v = dL/d(grad_mean) it also runs the forward-mode
+//                      tangent sweep hdot_l = relu'(h_l) * (hdot_{l-1} W_l^T) whose outer products with
+//                      the saved r_l give the second-order weight gradients (ReLU'' = 0 a.e.).
+//
+// Layer activations are written to HBM once (they are needed by the weight gradients and as ReLU
+// gates); at fp32-MFMA rate every layer GEMM is compute-bound (64 FLOP/B vs a 25 FLOP/B machine
+// balance), see DESIGN.md.
+#include "pn_common.h"
+#include <math.h>
+
+#define ST(s) ((hipStream_t)(s))
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+// -------------------------------------------------------------------------------- layouts
+PnLayout pn_layout(int nc) {
+    PnLayout L;
+    L.nc = nc;
+    int64_t o = 0;
+    for (int l = 0; l < 8; ++l) {
+        int k = (l == 0) ? PN_ENC_DIM : (l == 5 ? PN_WIDTH + PN_ENC_DIM : PN_WIDTH);
+        L.w[l] = o;
+        o += (int64_t)PN_WIDTH * k;
+        L.b[l] = o;
+        o += PN_WIDTH;
+    }
+    L.we = o; o += PN_WIDTH * PN_WIDTH;
+    L.be = o; o += PN_WIDTH;
+    L.wv = o; o += PN_WIDTH_COND * (PN_WIDTH + PN_VIEW_DIM);
+    L.bv = o; o += PN_WIDTH_COND;
+    L.wd = o; o += (int64_t)nc * PN_WIDTH;
+    L.wc = o; o += 3 * PN_WIDTH_COND;
+    L.bd = o; o += nc;
+    L.bc = o; o += 3;
+    L.total = o;
+    return L;
+}
+
+PnPack pn_pack_layout() {
+    PnPack P;
+    int64_t o = 0;
+    for (int l = 0; l < 8; ++l) {
+        P.wt[l] = o;
+        o += (int64_t)PN_WIDTH * ((l == 0) ? PN_ENC_DIM : PN_WIDTH);
+    }
+    P.w5e_t = o; o += PN_ENC_DIM * PN_WIDTH;
+    P.we_t = o; o += PN_WIDTH * PN_WIDTH;
+    P.wvm = o; o += PN_WIDTH_COND * PN_WIDTH;
+    P.wvm_t = o; o += PN_WIDTH * PN_WIDTH_COND;
+    P.wvv = o; o += PN_WIDTH_COND * 32;
+    P.total = o;
+    return P;
+}
+
+// dst[c][r] = src[r*ld + c0 + c]  for r < rows, c < cols   (dst leading dim = rows)
+__global__ void k_transpose(const float* src, int ld, int c0, int rows, int cols, float* dst) {
+    __shared__ float tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        int r = by + i, c = bx + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * ld + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        int c = bx + i, r = by + threadIdx.x;
+        if (r < rows && c < cols) dst[(int64_t)c * rows + r] = tile[threadIdx.x][i];
+    }
+}
+// dst[r][c] = (c < cols) ? src[r*ld + c0 + c] : 0   (dst leading dim = dcols)
+__global__ void k_copy_cols(const float* src, int ld, int c0, int rows, int cols, int dcols, float* dst) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * dcols) return;
+    int r = idx / dcols, c = idx % dcols;
+    dst[idx] = (c < cols) ? src[(int64_t)r * ld + c0 + c] : 0.f;
+}
+
+static int transpose_into(const float* src, int ld, int c0, int rows, int cols, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, src, ld, c0, rows, cols,
+                       dst);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+// -------------------------------------------------------------------------- narrow heads (VALU)
+// out[row,c] = b[c] + sum_k x[row,k] * W[c,k]      K = 64*VEC, one wavefront per row (grid-stride)
+template <int VEC, int NC>
+__global__ __launch_bounds__(256) void k_head_fwd(int64_t M, const float* x, int ldx, const float* W, const float* b,
+                                                   float* out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float w[NC][VEC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) w[c][v] = W[c * (64 * VEC) + lane * VEC + v];
+    for (int64_t row = wave; row < M; row += nwaves) {
+        float xv[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv[v] = x[row * ldx + lane * VEC + v];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s += xv[v] * w[c][v];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) out[row * ldo + c] = s + (b ? b[c] : 0.f);
+        }
+    }
+}
+
+// out[row,k] = sum_c d[row,c] * W[c,k]  (optionally gated by gate[row,k] > 0)
+template <int VEC, int NC>
+__global__ __launch_bounds__(256) void k_head_bwd_data(int64_t M, const float* d, int ldd, const float* W, float* out,
+                                                        int ldo, const float* gate, int ldg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float w[NC][VEC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) w[c][v] = W[c * (64 * VEC) + lane * VEC + v];
+    for (int64_t row = wave; row < M; row += nwaves) {
+        float dv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dv[c] = d[row * ldd + c];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) s += dv[c] * w[c][v];
+            if (gate && !(gate[row * ldg + lane * VEC + v] > 0.f)) s = 0.f;
+            out[row * ldo + lane * VEC + v] = s;
+        }
+    }
+}
+
+// partial[blk][c][k] = sum_{rows of blk} coef(row) * d[row,c] * x[row,k]; partial bias in [blk][NC*K + c]
+// coef(row) = coef ? coef[row] : 1
+template <int VEC, int NC>
+__global__ __launch_bounds__(256) void k_head_bwd_weight(int64_t M, int rows_per_block, const float* d, int ldd,
+                                                          const float* coef, const float* x, int ldx, float* partial) {
+    constexpr int K = 64 * VEC;
+    __shared__ float red[4][NC * K + NC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float acc[NC][VEC], bacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        bacc[c] = 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
+    }
+    for (int64_t row = r0 + wv; row < r1; row += 4) {
+        float cf = coef ? coef[row] : 1.f;
+        float xv[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv[v] = x[row * ldx + lane * VEC + v];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float dv = d[row * ldd + c] * cf;
+            bacc[c] += dv;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[c][v] += dv * xv[v];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[wv][c * K + lane * VEC + v] = acc[c][v];
+        if (lane == 0) red[wv][NC * K + c] = bacc[c];
+    }
+    __syncthreads();
+    float* out = partial + (int64_t)blockIdx.x * (NC * K + NC);
+    for (int i = threadIdx.x; i < NC * K + NC; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+// dst[j] (+)= sum_blk partial[blk][off + j], j < n     (dst strided by ldd per row of `cols`)
+__global__ void k_reduce_partial(const float* partial, int nblk_, int stride, int off, int rows, int cols, int src_ld,
+                                 float* dst, int ldd) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    int r = idx / cols, c = idx % cols;
+    float s = 0.f;
+    for (int b = 0; b < nblk_; ++b) s += partial[(int64_t)b * stride + off + r * src_ld + c];
+    dst[(int64_t)r * ldd + c] += s;
+}
+
+// column sums: partial[blk][col] = sum_{rows of blk} X[row, col]
+__global__ __launch_bounds__(256) void k_colsum(int64_t M, int rows_per_block, const float* X, int ldx, int N,
+                                                 float* partial) {
+    const int col = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s = 0.f;
+    if (col < N)
+        for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + col];
+    if (col < N) partial[(int64_t)blockIdx.x * N + col] = s;
+}
+
+// ------------------------------------------------------------------------------ small fused bits
+// per-view-row bias of the view layer: vb[r][j] = bv[j] + sum_i viewenc[r][i] * Wv[j][256 + i]
+__global__ void k_view_bias(int64_t R, const float* viewenc, const float* Wv, const float* bv, float* vb) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * PN_WIDTH_COND) return;
+    int64_t r = idx / PN_WIDTH_COND;
+    int j = (int)(idx % PN_WIDTH_COND);
+    const float* w = Wv + (int64_t)j * (PN_WIDTH + PN_VIEW_DIM) + PN_WIDTH;
+    float s = 0.f;
+    for (int i = 0; i < PN_VIEW_DIM; ++i) s += viewenc[r * PN_VIEW_DIM + i] * w[i];
+    vb[idx] = s + bv[j];
+}
+
+// VE[row][i] = viewenc[(row / rows_per_ray) % view_rows][i], padded to 32 columns
+__global__ void k_expand_viewenc(int64_t M, int rows_per_ray, int64_t view_rows, const float* viewenc, float* VE) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * 32) return;
+    int64_t row = idx >> 5;
+    int i = (int)(idx & 31);
+    int64_t r = (row / rows_per_ray) % view_rows;
+    VE[idx] = (i < PN_VIEW_DIM) ? viewenc[r * PN_VIEW_DIM + i] : 0.f;
+}
+
+__device__ __forceinline__ float sp_d1(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sp_d2(float x) {
+    if (x > 20.f) return 0.f;
+    float s = 1.f / (1.f + expf(-x));
+    return s * (1.f - s);
+}
+
+// seed of the density-gradient sweep: r7[row][j] = softplus'(z_row) * Wd[0][j] * [h7[row][j] > 0]
+__global__ void k_dgrad_seed(int64_t M, int nc, float bias, const float* raw_density, const float* Wd, const float* h7,
+                             float* r7) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * PN_WIDTH) return;
+    int64_t row = idx >> 8;
+    int j = (int)(idx & 255);
+    float s = sp_d1(raw_density[row * nc] + bias);
+    r7[idx] = (h7[idx] > 0.f) ? s * Wd[j] : 0.f;
+}
+
+// second-order seed: dden[row][0] += softplus''(z) * sdot[row];   coef[row] = softplus'(z)
+__global__ void k_second_order_seed(int64_t M, int nc, float bias, const float* raw_density, const float* sdot,
+                                    const float* dden_in, float* dden_out, float* coef) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * nc) return;
+    int64_t row = idx / nc;
+    int c = (int)(idx % nc);
+    float z = raw_density[row * nc] + bias;
+    float v = dden_in[idx];
+    if (c == 0) {
+        v += sp_d2(z) * sdot[row];
+        coef[row] = sp_d1(z);
+    }
+    dden_out[idx] = v;
+}
+
+// -------------------------------------------------------------------------------- GEMM sugar
+static PnGemmNt nt(int64_t M, int N, const float* A, int lda, const float* B, int ldb, int K, float* C, int ldc) {
+    PnGemmNt g{};
+    g.seg[0] = PnSeg{A, B, lda, ldb, K};
+    g.nseg = 1;
+    g.C = C;
+    g.ldc = ldc;
+    g.M = M;
+    g.N = N;
+    return g;
+}
+static void seg2(PnGemmNt& g, const float* A, int lda, const float* B, int ldb, int K) {
+    g.seg[1] = PnSeg{A, B, lda, ldb, K};
+    g.nseg = 2;
+}
+#define RUN(x)                  \
+    do {                        \
+        int rc_ = (x);          \
+        if (rc_ != PN_OK) return rc_; \
+    } while (0)
+
+template <int VEC, int NC>
+static int head_fwd(int64_t M, const float* x, int ldx, const float* W, const float* b, float* out, int ldo,
+                    hipStream_t s) {
+    hipLaunchKernelGGL((k_head_fwd<VEC, NC>), dim3(2048), dim3(256), 0, s, M, x, ldx, W, b, out, ldo);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+template <int VEC, int NC>
+static int head_bwd_data(int64_t M, const float* d, int ldd, const float* W, float* out, int ldo, const float* gate,
+                         int ldg, hipStream_t s) {
+    hipLaunchKernelGGL((k_head_bwd_data<VEC, NC>), dim3(2048), dim3(256), 0, s, M, d, ldd, W, out, ldo, gate, ldg);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+#define HEAD_ROWS 512
+// dW[NC][K] += sum coef * d^T x ; db[NC] += sum coef * d  (db may be null)
+template <int VEC, int NC>
+static int head_bwd_weight(int64_t M, const float* d, int ldd, const float* coef, const float* x, int ldx, float* dW,
+                           float* db, float* partial, hipStream_t s) {
+    constexpr int K = 64 * VEC;
+    int nb = (int)nblk(M, HEAD_ROWS);
+    hipLaunchKernelGGL((k_head_bwd_weight<VEC, NC>), dim3(nb), dim3(256), 0, s, M, HEAD_ROWS, d, ldd, coef, x, ldx,
+                       partial);
+    PN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_reduce_partial, dim3(nblk(NC * K, 256)), dim3(256), 0, s, partial, nb, NC * K + NC, 0, NC, K, K,
+                       dW, K);
+    PN_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(k_reduce_partial, dim3(1), dim3(256), 0, s, partial, nb, NC * K + NC, NC * K, 1, NC, NC, db, NC);
+        PN_CHECK_LAUNCH();
+    }
+    return PN_OK;
+}
+#define COLSUM_ROWS 256
+static int colsum_into(int64_t M, const float* X, int ldx, int N, float* dst, float* partial, hipStream_t s) {
+    int nb = (int)nblk(M, COLSUM_ROWS);
+    hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, M, COLSUM_ROWS, X, ldx, N, partial);
+    PN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_reduce_partial, dim3(1), dim3(256), 0, s, partial, nb, N, 0, 1, N, N, dst, N);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+static int wgrad(int64_t M, const float* X, int ldx, int N1, const float* Y, int ldy, int N2, float* dW, int ldw,
+                 float* work, hipStream_t s) {
+    PnSegTn sg{X, Y, ldx, ldy, M};
+    return pn_launch_gemm_tn(&sg, 1, N1, N2, dW, ldw, 1, work, s);
+}
+
+
+extern "C" {
+
+int64_t pn_param_layout(int nc, int64_t* off) {
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    PnLayout L = pn_layout(nc);
+    if (off) {
+        for (int l = 0; l < 8; ++l) {
+            off[2 * l] = L.w[l];
+            off[2 * l + 1] = L.b[l];
+        }
+        off[16] = L.we; off[17] = L.be; off[18] = L.wv; off[19] = L.bv;
+        off[20] = L.wd; off[21] = L.wc; off[22] = L.bd; off[23] = L.bc;
+    }
+    return L.total;
+}
+
+int64_t pn_wpack_floats(int nc) {
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    return pn_pack_layout().total;
+}
+
+int pn_pack_weights(const float* params, int nc, float* wpack, void* stream) {
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (!params || !wpack) return PN_ERR_NULL;
+    PnLayout L = pn_layout(nc);
+    PnPack P = pn_pack_layout();
+    hipStream_t s = ST(stream);
+    for (int l = 0; l < 8; ++l) {
+        int k = (l == 0) ? PN_ENC_DIM : (l == 5 ? PN_WIDTH + PN_ENC_DIM : PN_WIDTH);
+        int kk = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
+        RUN(transpose_into(params + L.w[l], k, 0, PN_WIDTH, kk, wpack + P.wt[l], s));  // [kk][256]
+    }
+    RUN(transpose_into(params + L.w[5], PN_WIDTH + PN_ENC_DIM, PN_WIDTH, PN_WIDTH, PN_ENC_DIM, wpack + P.w5e_t, s));
+    RUN(transpose_into(params + L.we, PN_WIDTH, 0, PN_WIDTH, PN_WIDTH, wpack + P.we_t, s));
+    const int ldv = PN_WIDTH + PN_VIEW_DIM;
+    hipLaunchKernelGGL(k_copy_cols, dim3(nblk(PN_WIDTH_COND * PN_WIDTH, 256)), dim3(256), 0, s, params + L.wv, ldv, 0,
+                       PN_WIDTH_COND, PN_WIDTH, PN_WIDTH, wpack + P.wvm);
+    PN_CHECK_LAUNCH();
+    RUN(transpose_into(params + L.wv, ldv, 0, PN_WIDTH_COND, PN_WIDTH, wpack + P.wvm_t, s));  // [256][128]
+    hipLaunchKernelGGL(k_copy_cols, dim3(nblk(PN_WIDTH_COND * 32, 256)), dim3(256), 0, s, params + L.wv, ldv, PN_WIDTH,
+                       PN_WIDTH_COND, PN_VIEW_DIM, 32, wpack + P.wvv);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, const float* params, const float* wpack,
+                   const float* mean, const float* cov, const float* viewdirs, float* enc, float* viewenc,
+                   float* viewbias, float* acts, float* raw_rgb, float* raw_density, void* stream) {
+    if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (!params || !wpack || !mean || !cov || !viewdirs || !enc || !viewenc || !viewbias || !acts || !raw_rgb ||
+        !raw_density)
+        return PN_ERR_NULL;
+    hipStream_t s = ST(stream);
+    PnLayout L = pn_layout(nc);
+    PnPack P = pn_pack_layout();
+    const int64_t Mp = pn_pad(M);
+    auto act = [&](int i) { return acts + (int64_t)i * Mp * PN_WIDTH; };
+
+    RUN(pn_ipe_encode(M, mean, cov, enc, stream));
+    RUN(pn_pos_enc_view(view_rows, viewdirs, viewenc, stream));
+    hipLaunchKernelGGL(k_view_bias, dim3(nblk(view_rows * PN_WIDTH_COND, 256)), dim3(256), 0, s, view_rows, viewenc,
+                       params + L.wv, params + L.bv, viewbias);
+    PN_CHECK_LAUNCH();
+
+    // trunk
+    for (int l = 0; l < 8; ++l) {
+        PnGemmNt g;
+        if (l == 0) {
+            g = nt(M, PN_WIDTH, enc, PN_ENC_DIM, params + L.w[0], PN_ENC_DIM, PN_ENC_DIM, act(0), PN_WIDTH);
+        } else if (l == 5) {
+            const int ld5 = PN_WIDTH + PN_ENC_DIM;
+            g = nt(M, PN_WIDTH, act(4), PN_WIDTH, params + L.w[5], ld5, PN_WIDTH, act(5), PN_WIDTH);
+            seg2(g, enc, PN_ENC_DIM, params + L.w[5] + PN_WIDTH, ld5, PN_ENC_DIM);
+        } else {
+            g = nt(M, PN_WIDTH, act(l - 1), PN_WIDTH, params + L.w[l], PN_WIDTH, PN_WIDTH, act(l), PN_WIDTH);
+        }
+        g.bias = params + L.b[l];
+        g.flags = PN_EPI_BIAS | PN_EPI_RELU;
+        RUN(pn_launch_gemm_nt(g, s));
+    }
+    // density head
+    if (nc == 5) RUN((head_fwd<4, 5>(M, act(7), PN_WIDTH, params + L.wd, params + L.bd, raw_density, 5, s)));
+    else RUN((head_fwd<4, 1>(M, act(7), PN_WIDTH, params + L.wd, params + L.bd, raw_density, 1, s)));
+    // bottleneck (no activation)
+    {
+        PnGemmNt g = nt(M, PN_WIDTH, act(7), PN_WIDTH, params + L.we, PN_WIDTH, PN_WIDTH, act(8), PN_WIDTH);
+        g.bias = params + L.be;
+        g.flags = PN_EPI_BIAS;
+        RUN(pn_launch_gemm_nt(g, s));
+    }
+    // view layer: relu(bott * Wv[:, :256]^T + (bv + viewenc * Wv[:, 256:]^T)[ray])
+    {
+        PnGemmNt g = nt(M, PN_WIDTH_COND, act(8), PN_WIDTH, wpack + P.wvm, PN_WIDTH, PN_WIDTH, act(9), PN_WIDTH);
+        g.rowbias = viewbias;
+        g.ldrb = PN_WIDTH_COND;
+        g.rows_per_ray = rows_per_ray;
+        g.rb_mod = view_rows;
+        g.flags = PN_EPI_ROWBIAS | PN_EPI_RELU;
+        RUN(pn_launch_gemm_nt(g, s));
+    }
+    RUN((head_fwd<2, 3>(M, act(9), PN_WIDTH, params + L.wc, params + L.bc, raw_rgb, 3, s)));
+    return PN_OK;
+}
+
+int pn_density_grad(int64_t M, int nc, float density_bias, const float* params, const float* wpack, const float* mean,
+                    const float* cov, const float* acts, const float* raw_density, float* rsweep, float* scratch,
+                    float* grad_mean, void* stream) {
+    if (M <= 0) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (!params || !wpack || !mean || !cov || !acts || !raw_density || !rsweep || !scratch || !grad_mean)
+        return PN_ERR_NULL;
+    hipStream_t s = ST(stream);
+    PnLayout L = pn_layout(nc);
+    PnPack P = pn_pack_layout();
+    const int64_t Mp = pn_pad(M);
+    auto act = [&](int i) { return acts + (int64_t)i * Mp * PN_WIDTH; };
+    auto rs = [&](int i) { return rsweep + (int64_t)i * Mp * PN_WIDTH; };
+    hipLaunchKernelGGL(k_dgrad_seed, dim3(nblk(M * PN_WIDTH, 256)), dim3(256), 0, s, M, nc, density_bias, raw_density,
+                       params + L.wd, act(7), rs(7));
+    PN_CHECK_LAUNCH();
+    for (int l = 7; l >= 1; --l) {  // r_{l-1} = [h_{l-1} > 0] * (r_l * W_l[:, :256])
+        PnGemmNt g = nt(M, PN_WIDTH, rs(l), PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, rs(l - 1), PN_WIDTH);
+        g.gate = act(l - 1);
+        g.ldg = PN_WIDTH;
+        g.flags = PN_EPI_GATE;
+        RUN(pn_launch_gemm_nt(g, s));
+    }
+    {  // d sigma / d enc = r_0 * W_0 + r_5 * W_5[:, 256:]
+        PnGemmNt g = nt(M, PN_ENC_DIM, rs(0), PN_WIDTH, wpack + P.wt[0], PN_WIDTH, PN_WIDTH, scratch, PN_ENC_DIM);
+        seg2(g, rs(5), PN_WIDTH, wpack + P.w5e_t, PN_WIDTH, PN_WIDTH);
+        RUN(pn_launch_gemm_nt(g, s));
+    }
+    RUN(pn_launch_ipe_backward(M, mean, cov, scratch, grad_mean, s));
+    return PN_OK;
+}
+
+int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows) {
+    const int64_t Mp = pn_pad(M);
+    int64_t n = 0;
+    n += 2 * Mp * PN_WIDTH;       // delta ping-pong
+    n += 2 * Mp * PN_WIDTH;       // tangent ping-pong
+    n += Mp * PN_WIDTH;           // head addend / d_bott
+    n += Mp * PN_WIDTH_COND;      // d view hidden
+    n += 2 * Mp * PN_ENC_DIM;     // edot, d_enc
+    n += Mp * 32;                 // expanded viewenc
+    n += Mp * 8 + Mp * 2;         // dden copy, sdot, coef
+    n += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);  // slabs
+    int64_t nb = (M + HEAD_ROWS - 1) / HEAD_ROWS;
+    int64_t hp = nb * (5 * PN_WIDTH + 5);
+    int64_t cp = ((M + COLSUM_ROWS - 1) / COLSUM_ROWS) * PN_WIDTH;
+    n += (hp > cp ? hp : cp) + 64;
+    (void)view_rows;
+    return n;
+}
+
+int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, float density_bias, const float* params,
+                    const float* wpack, const float* mean, const float* cov, const float* enc, const float* viewenc,
+                    const float* acts, const float* raw_density, const float* d_raw_rgb, const float* d_raw_density,
+                    const float* rsweep, const float* v_gradmean, float* d_mean, float* grads, float* work,
+                    void* stream) {
+    if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (!params || !wpack || !mean || !cov || !enc || !viewenc || !acts || !raw_density || !d_raw_rgb ||
+        !d_raw_density || !grads || !work)
+        return PN_ERR_NULL;
+    if (v_gradmean && !rsweep) return PN_ERR_NULL;
+    hipStream_t s = ST(stream);
+    PnLayout L = pn_layout(nc);
+    PnPack P = pn_pack_layout();
+    const int64_t Mp = pn_pad(M);
+    auto act = [&](int i) { return acts + (int64_t)i * Mp * PN_WIDTH; };
+    auto rs = [&](int i) { return rsweep + (int64_t)i * Mp * PN_WIDTH; };
+    // carve the workspace (every piece is a multiple of 4 floats -> 16-B aligned if `work` is)
+    float* w = work;
+    float* delta[2] = {w, w + Mp * PN_WIDTH};
+    w += 2 * Mp * PN_WIDTH;
+    float* tang[2] = {w, w + Mp * PN_WIDTH};
+    w += 2 * Mp * PN_WIDTH;
+    float* dbott = w; w += Mp * PN_WIDTH;
+    float* dvh = w; w += Mp * PN_WIDTH_COND;
+    float* edot = w; w += Mp * PN_ENC_DIM;
+    float* denc = w; w += Mp * PN_ENC_DIM;
+    float* VE = w; w += Mp * 32;
+    float* dden = w; w += Mp * 8;
+    float* sdot = w; w += Mp;
+    float* coef = w; w += Mp;
+    float* slab = w; w += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);
+    float* partial = w;
+    const int ld5 = PN_WIDTH + PN_ENC_DIM;
+    const int ldv = PN_WIDTH + PN_VIEW_DIM;
+
+    const float* dden_use = d_raw_density;
+    // ---------------- second-order path: tangent sweep + its weight gradients -----------------
+    if (v_gradmean) {
+        RUN(pn_launch_ipe_tangent(M, mean, cov, v_gradmean, edot, s));
+        const float* prev = edot;
+        int prev_ld = PN_ENC_DIM;
+        for (int l = 0; l < 8; ++l) {
+            // dW_l += r_l^T * hdot_{l-1}   (layer 5 also against edot for the skip columns)
+            int kin = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
+            int ldw = (l == 0) ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH);
+            RUN(wgrad(M, rs(l), PN_WIDTH, PN_WIDTH, prev, prev_ld, kin, grads + L.w[l], ldw, slab, s));
+            if (l == 5) RUN(wgrad(M, rs(5), PN_WIDTH, PN_WIDTH, edot, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, s));
+            // hdot_l = [h_l > 0] * (hdot_{l-1} * W_l^T)
+            float* cur = tang[l & 1];
+            PnGemmNt g;
+            if (l == 0) {
+                g = nt(M, PN_WIDTH, edot, PN_ENC_DIM, params + L.w[0], PN_ENC_DIM, PN_ENC_DIM, cur, PN_WIDTH);
+            } else if (l == 5) {
+                g = nt(M, PN_WIDTH, prev, PN_WIDTH, params + L.w[5], ld5, PN_WIDTH, cur, PN_WIDTH);
+                seg2(g, edot, PN_ENC_DIM, params + L.w[5] + PN_WIDTH, ld5, PN_ENC_DIM);
+            } else {
+                g = nt(M, PN_WIDTH, prev, PN_WIDTH, params + L.w[l], PN_WIDTH, PN_WIDTH, cur, PN_WIDTH);
+            }
+            g.gate = act(l);
+            g.ldg = PN_WIDTH;
+            g.flags = PN_EPI_GATE;
+            RUN(pn_launch_gemm_nt(g, s));
+            prev = cur;
+            prev_ld = PN_WIDTH;
+        }
+        // sigma_dot_raw = Wd[0] . hdot_7 ;  dWd[0] += sum softplus'(z) * hdot_7
+        RUN((head_fwd<4, 1>(M, prev, PN_WIDTH, params + L.wd, nullptr, sdot, 1, s)));
+        hipLaunchKernelGGL(k_second_order_seed, dim3(nblk(M * nc, 256)), dim3(256), 0, s, M, nc, density_bias,
+                           raw_density, sdot, d_raw_density, dden, coef);
+        PN_CHECK_LAUNCH();
+        dden_use = dden;
+        // x = hdot_7, d = ones scaled by coef: reuse head_bwd_weight with d = coef as a 1-channel "gradient"
+        RUN((head_bwd_weight<4, 1>(M, coef, 1, nullptr, prev, PN_WIDTH, grads + L.wd, nullptr, partial, s)));
+    }
+
+    // ---------------- colour head + view layer ------------------------------------------------
+    RUN((head_bwd_weight<2, 3>(M, d_raw_rgb, 3, nullptr, act(9), PN_WIDTH, grads + L.wc, grads + L.bc, partial, s)));
+    RUN((head_bwd_data<2, 3>(M, d_raw_rgb, 3, params + L.wc, dvh, PN_WIDTH_COND, act(9), PN_WIDTH, s)));
+    RUN(wgrad(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, act(8), PN_WIDTH, PN_WIDTH, grads + L.wv, ldv, slab, s));
+    hipLaunchKernelGGL(k_expand_viewenc, dim3(nblk(M * 32, 256)), dim3(256), 0, s, M, rows_per_ray, view_rows, viewenc,
+                       VE);
+    PN_CHECK_LAUNCH();
+    {
+        PnSegTn sg{dvh, VE, PN_WIDTH_COND, 32, M};
+        // [128][32] product; only the first 27 columns exist in the parameter: land it in scratch, then add
+        float* tmp = partial;  // 128*32 floats
+        RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, tmp, 32, 0, slab, s));
+        hipLaunchKernelGGL(k_reduce_partial, dim3(nblk(PN_WIDTH_COND * PN_VIEW_DIM, 256)), dim3(256), 0, s, tmp, 1, 0, 0,
+                           PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv);
+        PN_CHECK_LAUNCH();
+    }
+    RUN(colsum_into(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv, partial, s));
+    {  // d bottleneck = dvh * Wv[:, :256]
+        PnGemmNt g = nt(M, PN_WIDTH, dvh, PN_WIDTH_COND, wpack + P.wvm_t, PN_WIDTH_COND, PN_WIDTH_COND, dbott, PN_WIDTH);
+        RUN(pn_launch_gemm_nt(g, s));
+    }
+    RUN(wgrad(M, dbott, PN_WIDTH, PN_WIDTH, act(7), PN_WIDTH, PN_WIDTH, grads + L.we, PN_WIDTH, slab, s));
+    RUN(colsum_into(M, dbott, PN_WIDTH, PN_WIDTH, grads + L.be, partial, s));
+    // ---------------- density head ----------------------------------------------------------
+    float* d7 = delta[1];
+    if (nc == 5) {
+        RUN((head_bwd_weight<4, 5>(M, dden_use, 5, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, s)));
+        RUN((head_bwd_data<4, 5>(M, dden_use, 5, params + L.wd, delta[0], PN_WIDTH, nullptr, 0, s)));
+    } else {
+        RUN((head_bwd_weight<4, 1>(M, dden_use, 1, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, s)));
+        RUN((head_bwd_data<4, 1>(M, dden_use, 1, params + L.wd, delta[0], PN_WIDTH, nullptr, 0, s)));
+    }
+    {  // delta_7 = [h7 > 0] * (d_bott * We + d_raw_density * Wd)
+        PnGemmNt g = nt(M, PN_WIDTH, dbott, PN_WIDTH, wpack + P.we_t, PN_WIDTH, PN_WIDTH, d7, PN_WIDTH);
+        g.addc = delta[0];
+        g.ldadd = PN_WIDTH;
+        g.gate = act(7);
+        g.ldg = PN_WIDTH;
+        g.flags = PN_EPI_ADDC | PN_EPI_GATE;
+        RUN(pn_launch_gemm_nt(g, s));
+    }
+    // ---------------- trunk ---------------------------------------------------------------------
+    float* cur = d7;
+    float* d5 = nullptr;
+    for (int l = 7; l >= 0; --l) {
+        const float* xin = (l == 0) ? enc : act(l - 1);
+        int ldx = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
+        int kin = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
+        int ldw = (l == 0) ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH);
+        RUN(wgrad(M, cur, PN_WIDTH, PN_WIDTH, xin, ldx, kin, grads + L.w[l], ldw, slab, s));
+        if (l == 5) RUN(wgrad(M, cur, PN_WIDTH, PN_WIDTH, enc, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, s));
+        RUN(colsum_into(M, cur, PN_WIDTH, PN_WIDTH, grads + L.b[l], partial, s));
+        if (l == 5 && d_mean) {
+            // keep delta_5 alive for the d_enc GEMM: park it in the tangent buffer (free by now)
+            if (hipMemcpyAsync(tang[0], cur, sizeof(float) * M * PN_WIDTH, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return PN_ERR_HIP;
+            d5 = tang[0];
+        }
+        if (l > 0) {
+            float* nxt = (cur == delta[0]) ? delta[1] : delta[0];
+            PnGemmNt g = nt(M, PN_WIDTH, cur, PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, nxt, PN_WIDTH);
+            g.gate = act(l - 1);
+            g.ldg = PN_WIDTH;
+            g.flags = PN_EPI_GATE;
+            RUN(pn_launch_gemm_nt(g, s));
+            cur = nxt;
+        }
+    }
+    if (d_mean) {  // d enc = delta_0 * W_0 + delta_5 * W_5[:, 256:]  ->  d mean
+        PnGemmNt g = nt(M, PN_ENC_DIM, cur, PN_WIDTH, wpack + P.wt[0], PN_WIDTH, PN_WIDTH, denc, PN_ENC_DIM);
+        seg2(g, d5, PN_WIDTH, wpack + P.w5e_t, PN_WIDTH, PN_WIDTH);
+        RUN(pn_launch_gemm_nt(g, s));
+        RUN(pn_launch_ipe_backward(M, mean, cov, denc, d_mean, s));
+    }
+    return PN_OK;
+}
+
+int pn_gemm_nt(int64_t M, int N, int K, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
+               const float* bias, const float* gate, int ldg, int flags, void* stream) {
+    PnGemmNt g = nt(M, N, A, lda, Bt, ldb, K, C, ldc);
+    g.bias = bias;
+    g.gate = gate;
+    g.ldg = ldg;
+    g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE);
+    return pn_launch_gemm_nt(g, ST(stream));
+}
+
+int64_t pn_gemm_tn_work_floats(int64_t M, int N1, int N2) { return pn_tn_work_floats(M, N1, N2); }
+
+int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* Y, int ldy, float* C, int ldc,
+               int accumulate, float* work, void* stream) {
+    PnSegTn sg{X, Y, ldx, ldy, M};
+    return pn_launch_gemm_tn(&sg, 1, N1, N2, C, ldc, accumulate, work, ST(stream));
+}
+
+const char* pn_strerror(int code) {
+    switch (code) {
+        case PN_OK: return "ok";
+        case PN_ERR_BAD_SHAPE: return "bad shape / alignment";
+        case PN_ERR_UNSUPPORTED: return "unsupported configuration";
+        case PN_ERR_NULL: return "required pointer is null";
+        case PN_ERR_HIP: return "HIP launch failed";
+        default: return "unknown error";
+    }
+}
+int pn_abi_version(void) { return 1; }
+int64_t pn_pad_rows(int64_t m) { return pn_pad(m); }
+
+}  // extern "C"

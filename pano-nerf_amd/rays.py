@@ -1,0 +1,64 @@
+"""Ray containers and on-device ray generation.
+
+``Rays`` is the reference's batch container (datasets/base_datasets.py:13-16).  ``generate_pano_rays``
+and ``generate_lit_rays`` stand in for ``PanoDataset._generate_rays`` / ``.generate_lit_rays``
+(datasets/pano_datasets.py:152-216, 218-263; == utils/sampling.py:5-38) and run as HIP kernels, so a
+ray pool can be regenerated in HBM from (camera, pixel) instead of being shipped from the host.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import _lib
+
+Rays = collections.namedtuple(
+    "Rays", ("origins", "directions", "viewdirs", "radii", "lossmult", "near", "far", "noise_var"))
+Rays_keys = Rays._fields
+_DIMS = (3, 3, 3, 1, 1, 1, 1, 1)
+
+
+def namedtuple_map(fn, tup):
+    return type(tup)(*map(fn, tup))
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def generate_pano_rays(h, w, c2w, near=0.0, far=10.0, device="cuda"):
+    """One equirectangular camera -> Rays of [h*w, C] fp32 device tensors (row-major pixels)."""
+    device = torch.device(device)
+    c = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(-1))
+    if c.size != 16:
+        raise ValueError("c2w must be a 4x4 matrix")
+    out = [torch.empty(h * w, d, dtype=torch.float32, device=device) for d in _DIMS]
+    with torch.cuda.device(device):
+        _lib.call("pn_raygen_pano", int(h), int(w), c.ctypes.data, float(near), float(far),
+                  *[t.data_ptr() for t in out], _stream(device))
+    return Rays(*out)
+
+
+def pano_pixel_radius(rays):
+    """The constant pixel radius of a pano (datasets/pano_datasets.py:215)."""
+    return float(rays.radii[0, 0])
+
+
+def generate_lit_rays(num, radius, near=0.0, far=10.0, device="cuda"):
+    """`num` golden-spiral light rays as fp16 tensors, like the reference's env_rays."""
+    device = torch.device(device)
+    buf = torch.empty(14 * num, dtype=torch.float16, device=device)
+    with torch.cuda.device(device):
+        _lib.call("pn_lit_rays", int(num), float(radius), float(near), float(far), buf.data_ptr(), _stream(device))
+    v3 = buf[:9 * num].view(3, num, 3)
+    s = buf[9 * num:].view(5, num, 1)
+    return Rays(v3[0], v3[1], v3[2], s[0], s[1], s[2], s[3], s[4])
+
+
+def rearrange_render_image(rays, chunk_size=4096):
+    """models/mip.py:530-547: flatten [1,H,W,C] rays and slice into chunks."""
+    flat = [getattr(rays, k).reshape(-1, getattr(rays, k).shape[-1]) for k in Rays_keys]
+    val_mask = flat[-3]
+    n = flat[0].shape[0]
+    chunks = [Rays(*[a[i:i + chunk_size] for a in flat]) for i in range(0, n, chunk_size)]
+    return chunks, val_mask

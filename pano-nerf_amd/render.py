@@ -1,0 +1,315 @@
+"""PanoMipNeRF / MipNeRF — drop-in modules for the reference's ``models/pano_mip_nerf.py`` and
+``models/mip_nerf.py`` (same constructor keywords, same ``.mlp`` state-dict keys, same ``forward``
+keywords and returned tuples), evaluated by hand-written HIP kernels through the C ABI of
+``libpanonerf_hip.so``.  PyTorch is used for device memory, the current stream and autograd glue
+only: the whole render (both levels, normals, env light, surface) is ONE ``autograd.Function`` whose
+backward calls the hand-written adjoint kernels, including the second-order path through the
+density-gradient normals.
+
+There is no CPU / eager fallback: tensors must live on a HIP device and the library must be built.
+"""
+import torch
+
+from . import _lib
+from .mlp import RadianceMLP
+from .rays import Rays
+
+_NAMES9 = ("comp_rgb", "distance", "ort_loss", "normal", "albedo", "roughness", "surface_rgb", "diffuse", "shading")
+
+
+def _f32(x):
+    return x.detach().to(torch.float32).contiguous()
+
+
+class _Eval:
+    """Buffers of one MLP evaluation over M sample rows (all caller-owned HBM)."""
+
+    def __init__(self, M, rows_per_ray, viewdirs, nc, dev):
+        self.M, self.rows_per_ray, self.nc = M, rows_per_ray, nc
+        self.view_rows = viewdirs.shape[0]
+        self.viewdirs = viewdirs
+        Mp = int(_lib.load().pn_pad_rows(M))
+        self.Mp = Mp
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.mean, self.cov = e(M, 3), e(M, 3)
+        self.enc = e(Mp, 96)
+        self.viewenc, self.viewbias = e(self.view_rows, 27), e(self.view_rows, 128)
+        self.acts = e(10, Mp, 256)
+        self.raw_rgb, self.raw_den = e(M, 3), e(M, nc)
+        self.t = None
+        self.rsweep = None
+        self.gmean = None
+
+
+class _Cfg:
+    """Static configuration of one render call."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _mlp_forward(ev, params, wpack, st):
+    _lib.call("pn_mlp_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, params.data_ptr(), wpack.data_ptr(),
+              ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
+              ev.viewbias.data_ptr(), ev.acts.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), st)
+
+
+def _composite_forward(ev, R, N, cfg, white, dirs, dir_mod, st):
+    dev = ev.raw_rgb.device
+    comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    dist = torch.empty(R, dtype=torch.float32, device=dev)
+    acc = torch.empty(R, dtype=torch.float32, device=dev)
+    w = torch.empty(R, N, dtype=torch.float32, device=dev)
+    _lib.call("pn_composite_forward", R, N, ev.nc, cfg.density_bias, cfg.rgb_padding, int(white), ev.raw_rgb.data_ptr(),
+              ev.raw_den.data_ptr(), ev.t.data_ptr(), dirs.data_ptr(), dir_mod, comp.data_ptr(), dist.data_ptr(),
+              acc.data_ptr(), w.data_ptr(), st)
+    return comp, dist, acc, w
+
+
+def _composite_backward(ev, R, N, cfg, white, dirs, dir_mod, d_comp, d_dist, d_w, d_raw_rgb, d_raw_den, st):
+    _lib.call("pn_composite_backward", R, N, ev.nc, cfg.density_bias, cfg.rgb_padding, int(white),
+              ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), ev.t.data_ptr(), dirs.data_ptr(), dir_mod,
+              d_comp.data_ptr(), _lib.ptr(d_dist), _lib.ptr(d_w), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(), st)
+
+
+def _mlp_backward(ev, cfg, params, wpack, d_raw_rgb, d_raw_den, v, d_mean, flat_grad, st):
+    n = int(_lib.load().pn_mlp_backward_work_floats(ev.M, ev.view_rows))
+    work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
+    _lib.call("pn_mlp_backward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, cfg.density_bias, params.data_ptr(),
+              wpack.data_ptr(), ev.mean.data_ptr(), ev.cov.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
+              ev.acts.data_ptr(), ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(),
+              _lib.ptr(ev.rsweep), _lib.ptr(v), _lib.ptr(d_mean), flat_grad.data_ptr(), work.data_ptr(), st)
+
+
+class _RenderFn(torch.autograd.Function):
+    """(rays, env rays, noise, 24 parameters) -> the ten differentiable outputs of both levels."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, cfg, mlp, o, d, vd, radii, near, far, env_d, env_rad, env_near, env_far, env_omega, t_rand,
+                u_rand, env_rand, *plist):
+        dev = o.device
+        if dev.type != "cuda":
+            raise RuntimeError("pano_nerf_amd renders on a HIP device only (tensors are on %s); there is no CPU "
+                               "fallback" % dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            params = mlp.flat_params()
+            wpack = mlp.packed(st)
+            B, N, nc = o.shape[0], cfg.num_samples, cfg.nc
+            S, M = N + 1, o.shape[0] * cfg.num_samples
+            e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            # ---- level 0: stratified samples
+            e0 = _Eval(M, N, vd, nc, dev)
+            e0.t = e(B, S)
+            _lib.call("pn_sample_coarse", B, N, o.data_ptr(), d.data_ptr(), radii.data_ptr(), near.data_ptr(),
+                      far.data_ptr(), _lib.ptr(t_rand), e0.t.data_ptr(), e0.mean.data_ptr(), e0.cov.data_ptr(), st)
+            _mlp_forward(e0, params, wpack, st)
+            comp0, dist0, _, w0 = _composite_forward(e0, B, N, cfg, cfg.white_bkgd, d, B, st)
+            # ---- level 1: PDF resample (no gradient through the weights: stop_resample_grad)
+            e1 = _Eval(M, N, vd, nc, dev)
+            e1.t = e(B, S)
+            _lib.call("pn_resample", B, N, e0.t.data_ptr(), w0.data_ptr(), cfg.resample_padding, _lib.ptr(u_rand),
+                      o.data_ptr(), d.data_ptr(), radii.data_ptr(), e1.t.data_ptr(), e1.mean.data_ptr(),
+                      e1.cov.data_ptr(), st)
+            _mlp_forward(e1, params, wpack, st)
+            comp1, dist1, _, w1 = _composite_forward(e1, B, N, cfg, cfg.white_bkgd, d, B, st)
+            normal = ort = albedo = surface = diffuse = shading = None
+            ee = env_rgb = None
+            if cfg.normals:
+                e1.rsweep = e(8, e1.Mp, 256)
+                e1.gmean = e(M, 3)
+                scratch = e(e1.Mp, 96)
+                _lib.call("pn_density_grad", M, nc, cfg.density_bias, params.data_ptr(), wpack.data_ptr(),
+                          e1.mean.data_ptr(), e1.cov.data_ptr(), e1.acts.data_ptr(), e1.raw_den.data_ptr(),
+                          e1.rsweep.data_ptr(), scratch.data_ptr(), e1.gmean.data_ptr(), st)
+                normal = e(B, 3)
+                ort_ray = e(B) if cfg.use_ort else None
+                albedo = e(B, 3) if (cfg.surf and nc == 5) else None
+                _lib.call("pn_surf_gather_forward", B, N, nc, e1.gmean.data_ptr(), w1.data_ptr(), e1.raw_den.data_ptr(),
+                          d.data_ptr(), normal.data_ptr(), _lib.ptr(ort_ray), _lib.ptr(albedo), st)
+                if cfg.use_ort:
+                    ort = ort_ray.mean()
+            if cfg.surf:
+                D, Ne = env_d.shape[0], cfg.num_env_samples
+                ee = _Eval(B * D * Ne, Ne, env_d, nc, dev)
+                ee.t = e(B * D, Ne + 1)
+                _lib.call("pn_sample_env", B, D, Ne, o.data_ptr(), d.data_ptr(), dist1.data_ptr(), env_d.data_ptr(),
+                          env_rad.data_ptr(), env_near.data_ptr(), env_far.data_ptr(), _lib.ptr(env_rand),
+                          ee.t.data_ptr(), ee.mean.data_ptr(), ee.cov.data_ptr(), st)
+                _mlp_forward(ee, params, wpack, st)
+                env_rgb, _, _, _ = _composite_forward(ee, B * D, Ne, cfg, False, env_d, D, st)
+                diffuse, shading = e(B, 3), e(B, 3)
+                _lib.call("pn_surface_forward", B, D, env_rgb.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
+                          env_d.data_ptr(), env_omega.data_ptr(), diffuse.data_ptr(), shading.data_ptr(), st)
+                surface = diffuse.clone()
+        ctx.cfg, ctx.mlp = cfg, mlp
+        ctx.pack = (o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, albedo, normal, params, wpack)
+        outs = (comp0, dist0, comp1, dist1, ort, normal, albedo, surface, diffuse, shading)
+        ctx.present = [x is not None for x in outs]
+        return tuple(x if x is not None else torch.zeros((), device=dev) for x in outs)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_comp0, g_dist0, g_comp1, g_dist1, g_ort, g_normal, g_albedo, g_surface, g_diffuse, g_shading):
+        cfg, mlp = ctx.cfg, ctx.mlp
+        o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, albedo, normal, params, wpack = ctx.pack
+        dev = o.device
+        B, N, nc = o.shape[0], cfg.num_samples, cfg.nc
+        M = B * N
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        gz = lambda g, *s: _f32(g) if g is not None else z(*s)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            flat_grad = z(params.numel())
+            d_dist1 = gz(g_dist1, B).clone()
+            d_normal = gz(g_normal, B, 3) if cfg.normals else None
+            d_albedo = None
+            if cfg.surf:
+                D, Ne = env_d.shape[0], cfg.num_env_samples
+                d_dif = gz(g_surface, B, 3) + gz(g_diffuse, B, 3)
+                d_shd = gz(g_shading, B, 3)
+                d_env, d_alb_s, d_nrm_s = z(B, D, 3), z(B, 3), z(B, 3)
+                _lib.call("pn_surface_backward", B, D, env_rgb.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
+                          env_d.data_ptr(), env_omega.data_ptr(), d_dif.data_ptr(), d_shd.data_ptr(), d_env.data_ptr(),
+                          d_alb_s.data_ptr(), d_nrm_s.data_ptr(), st)
+                d_albedo = gz(g_albedo, B, 3) + d_alb_s
+                d_normal = d_normal + d_nrm_s
+                d_rr, d_rd = z(ee.M, 3), z(ee.M, nc)
+                _composite_backward(ee, B * D, Ne, cfg, False, env_d, D, d_env, None, None, d_rr, d_rd, st)
+                d_mean_e = z(ee.M, 3)
+                _mlp_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, flat_grad, st)
+                _lib.call("pn_env_origin_backward", B, D * Ne, d_mean_e.data_ptr(), d.data_ptr(), d_dist1.data_ptr(), st)
+            d_rr, d_rd = z(M, 3), z(M, nc)
+            d_w1 = v = None
+            if cfg.normals:
+                d_w1, v = z(B, N), z(M, 3)
+                d_ort_ray = None
+                if cfg.use_ort and g_ort is not None:
+                    d_ort_ray = (_f32(g_ort) / B).expand(B).contiguous()
+                _lib.call("pn_surf_gather_backward", B, N, nc, e1.gmean.data_ptr(), w1.data_ptr(),
+                          e1.raw_den.data_ptr(), d.data_ptr(), d_normal.data_ptr(), _lib.ptr(d_ort_ray),
+                          _lib.ptr(d_albedo), d_w1.data_ptr(), v.data_ptr(), d_rd.data_ptr(), st)
+            _composite_backward(e1, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp1, B, 3), d_dist1, d_w1, d_rr, d_rd, st)
+            _mlp_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, flat_grad, st)
+            d_rr0, d_rd0 = z(M, 3), z(M, nc)
+            _composite_backward(e0, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp0, B, 3), gz(g_dist0, B), None, d_rr0,
+                                d_rd0, st)
+            _mlp_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, flat_grad, st)
+        mlp.last_flat_grad = flat_grad
+        ctx.pack = None
+        return (None,) * 16 + tuple(mlp.grad_views(flat_grad))
+
+
+class _RenderBase(torch.nn.Module):
+    """Constructor keywords of models/pano_mip_nerf.py:120-151 / models/mip_nerf.py:108-134."""
+
+    _NC = 5
+
+    def __init__(self, num_samples=128, num_levels=2, resample_padding=0.01, stop_resample_grad=True,
+                 use_viewdirs=True, disparity=False, ray_shape="cone", min_deg_point=0, max_deg_point=16, deg_view=4,
+                 density_activation="softplus", density_noise=0.0, density_bias=-1.0, rgb_activation="sigmoid",
+                 alb_activation="sigmoid", rgb_padding=0.001, disable_integration=False, append_identity=True,
+                 mlp_net_depth=8, mlp_net_width=256, mlp_net_depth_condition=1, mlp_net_width_condition=128,
+                 mlp_skip_index=4, mlp_num_rgb_channels=3, mlp_num_density_channels=1, mlp_net_activation="relu",
+                 solid_angle_height=8, solid_angle_width=16, num_env_samples=10, **kwargs):
+        super().__init__()
+        # same error behaviour as the reference for the strings it rejects
+        if rgb_activation != "softplus":
+            raise NotImplementedError  # models/pano_mip_nerf.py:174-177
+        if self._NC == 5 and alb_activation != "sigmoid":
+            raise NotImplementedError  # :178-181
+        if density_activation != "softplus":
+            raise NotImplementedError  # :183-186
+        if ray_shape == "cylinder":
+            raise NotImplementedError  # models/mip.py:83-84
+        assert ray_shape == "cone"  # models/mip.py:86
+        unsupported = []
+        if num_levels != 2: unsupported.append("num_levels != 2")
+        if not stop_resample_grad: unsupported.append("stop_resample_grad=False")
+        if not use_viewdirs: unsupported.append("use_viewdirs=False")
+        if disparity: unsupported.append("disparity=True")
+        if disable_integration: unsupported.append("disable_integration=True")
+        if density_noise and density_noise > 0: unsupported.append("density_noise > 0")
+        if (min_deg_point, max_deg_point, deg_view) != (0, 16, 4): unsupported.append("encoding degrees != (0,16,4)")
+        if not append_identity: unsupported.append("append_identity=False")
+        if num_samples > 512 or num_samples < 2: unsupported.append("num_samples outside [2, 512]")
+        if unsupported:
+            raise NotImplementedError("pano_nerf_amd HIP path supports the configurations of configs/*.yaml only: "
+                                      + ", ".join(unsupported))
+        self.num_samples, self.num_levels = int(num_samples), int(num_levels)
+        self.resample_padding = float(resample_padding)
+        self.density_bias, self.rgb_padding = float(density_bias), float(rgb_padding)
+        self.num_env_samples = int(num_env_samples)
+        self.mlp = RadianceMLP(mlp_net_depth, mlp_net_width, mlp_net_depth_condition, mlp_net_width_condition,
+                               mlp_skip_index, mlp_num_rgb_channels, mlp_num_density_channels, mlp_net_activation,
+                               (max_deg_point - min_deg_point) * 6, deg_view * 6 + 3)
+        if self.mlp.num_density_channels != self._NC:
+            raise NotImplementedError(f"{type(self).__name__} needs mlp_num_density_channels={self._NC}")
+        self.noise_override = None  # tests: dict(t_rand=[B,S], u_rand=[B,S], env_rand=[1,Ne+1])
+
+    def _noise(self, randomized, B, dev, want_env):
+        if not randomized:
+            return None, None, None
+        S = self.num_samples + 1
+        ov = self.noise_override
+        if ov is not None:
+            g = lambda k: _f32(ov[k].to(dev)) if ov.get(k) is not None else None
+            return g("t_rand"), g("u_rand"), (g("env_rand") if want_env else None)
+        # same draws, same order and shapes as the reference: rand(B,S), uniform_(B,S), rand(1,Ne+1)
+        t_rand = torch.rand(B, S, device=dev)
+        u_rand = torch.empty(B, S, device=dev).uniform_(to=1.0 / S - torch.finfo(torch.float32).eps)
+        env_rand = torch.rand(1, self.num_env_samples + 1, device=dev) if want_env else None
+        return t_rand, u_rand, env_rand
+
+    def _run(self, rays, env_rays, randomized, white_bkgd, surf, use_ort, normals):
+        o, d, vd = _f32(rays.origins), _f32(rays.directions), _f32(rays.viewdirs)
+        radii, near, far = _f32(rays.radii).reshape(-1), _f32(rays.near).reshape(-1), _f32(rays.far).reshape(-1)
+        dev = o.device
+        if env_rays is not None and surf:
+            env = [_f32(env_rays.directions.to(dev)), _f32(env_rays.radii.to(dev)).reshape(-1),
+                   _f32(env_rays.near.to(dev)).reshape(-1), _f32(env_rays.far.to(dev)).reshape(-1),
+                   _f32(env_rays.lossmult.to(dev)).reshape(-1)]
+        else:
+            env = [torch.zeros(1, 3, device=dev)] + [torch.zeros(1, device=dev)] * 4
+        t_rand, u_rand, env_rand = self._noise(randomized, o.shape[0], dev, surf)
+        cfg = _Cfg(num_samples=self.num_samples, nc=self._NC, density_bias=self.density_bias,
+                   rgb_padding=self.rgb_padding, resample_padding=self.resample_padding,
+                   white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
+                   num_env_samples=self.num_env_samples)
+        plist = [p for _, p in self.mlp.named_in_order()]
+        outs = _RenderFn.apply(cfg, self.mlp, o, d, vd, radii, near, far, *env, t_rand, u_rand,
+                               None if env_rand is None else env_rand.reshape(-1), *plist)
+        return outs, cfg
+
+
+class PanoMipNeRF(_RenderBase):
+    """Drop-in for models/pano_mip_nerf.py:117 (forward at :197-363)."""
+
+    _NC = 5
+
+    def forward(self, rays: Rays, env_rays: Rays, randomized: bool, white_bkgd: bool, enable_surf: bool,
+                use_ort_loss: bool):
+        outs, cfg = self._run(rays, env_rays, randomized, white_bkgd, enable_surf, use_ort_loss, True)
+        comp0, dist0, comp1, dist1, ort, normal, albedo, surface, diffuse, shading = outs
+        lvl0 = (comp0, dist0, None, None, None, None, None, None, None)
+        if not cfg.surf:
+            albedo = surface = diffuse = shading = None
+        lvl1 = (comp1, dist1, ort if cfg.use_ort else None, normal, albedo, None, surface, diffuse, shading)
+        return [lvl0, lvl1]
+
+
+class MipNeRF(_RenderBase):
+    """Drop-in for models/mip_nerf.py:105 (forward at :170-283)."""
+
+    _NC = 1
+
+    def forward(self, rays: Rays, randomized: bool, white_bkgd: bool, use_ort_loss: bool):
+        outs, cfg = self._run(rays, None, randomized, white_bkgd, False, use_ort_loss, bool(use_ort_loss))
+        comp0, dist0, comp1, dist1, ort, normal = outs[:6]
+        lvl0 = (comp0, dist0, None, torch.ones_like(comp0))
+        if use_ort_loss:
+            lvl1 = (comp1, dist1, ort, normal)
+        else:
+            lvl1 = (comp1, dist1, None, torch.ones_like(comp1))
+        return [lvl0, lvl1]

@@ -1,0 +1,227 @@
+"""GPU parity of the drop-in modules: PanoMipNeRF / MipNeRF forward tuples, training loss and parameter
+gradients against the golden vectors captured from the reference; chunked full-image render;
+size-independent properties at the bench size."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import pano_oracle as orc
+
+pytestmark = pytest.mark.gpu
+CASES = ["B64_N32", "B16_N128"]
+NAMES9 = ("comp_rgb", "distance", "ort_loss", "normal", "albedo", "roughness", "surface_rgb", "diffuse", "shading")
+# outputs derived from the density gradient: the reference fp32 disagrees with its own fp64 run by up to
+# 6.5e-2 abs, so they are gated on median + vs-fp64 criteria instead of a pointwise 1e-4
+LOOSE = ("normal", "surface_rgb", "diffuse", "shading", "ort_loss")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_dev(rays):
+    return type(rays)(*[x.to(dev()) for x in rays])
+
+
+def rays_of(g):
+    return orc.Rays(*[torch.from_numpy(g["ray_" + k]) for k in orc.Rays._fields])
+
+
+def env_of(golden):
+    g = golden("raygen_8x16")
+    return orc.Rays(*[torch.from_numpy(g["env_" + k]) for k in orc.Rays._fields])
+
+
+def make_pano(N, nc=5):
+    import pano_nerf_amd as pn
+    cls = pn.PanoMipNeRF if nc == 5 else pn.MipNeRF
+    m = cls(num_samples=N, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=nc, num_env_samples=10)
+    m.mlp.load_state_dict(orc.init_params(4, nc))
+    return m.to(dev())
+
+
+def check_tuple(outs, g, prefix, names, g64=None):
+    for lvl, tup in enumerate(outs):
+        for nme, v in zip(names, tup):
+            key = f"{prefix}/l{lvl}/{nme}"
+            if v is None:
+                assert key not in g, key
+                continue
+            assert key in g, key
+            got = v.detach().cpu().numpy()
+            e = rel_err(got, g[key])
+            if nme in LOOSE and lvl == 1:
+                assert e < 5e-2, (key, e)
+                if got.ndim > 0:
+                    med = float(np.median(np.abs(got - g[key]) / (np.abs(g[key]) + 1e-6)))
+                    assert med < 1e-4, (key, med)
+                k64 = f"val64/l1/{nme}"
+                if g64 is not None and k64 in g64 and prefix == "val":
+                    ours = float(np.max(np.abs(got - g64[k64])))
+                    theirs = float(np.max(np.abs(g[key] - g64[k64])))
+                    assert ours <= 2 * theirs + 1e-5, (key, ours, theirs)
+            else:
+                assert e < 1e-4, (key, e)
+
+
+def check_grads(model, g, prefix):
+    for k, p in model.mlp.named_parameters():
+        ref_norm = float(g[f"{prefix}/grad/{k}/norm"])
+        got = p.grad.detach().cpu().reshape(-1)
+        assert torch.isfinite(got).all(), k
+        assert abs(float(got.double().norm()) - ref_norm) < 2e-2 * ref_norm + 1e-9, (k, float(got.double().norm()), ref_norm)
+        idx, ref = g[f"{prefix}/grad/{k}/idx"], g[f"{prefix}/grad/{k}/val"]
+        err = np.abs(got[idx].numpy() - ref)
+        assert float(np.median(err)) < 1e-3 * max(float(np.max(np.abs(ref))), 1e-12), (k, float(np.median(err)))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_pano_forward_loss_grads(golden, case):
+    import pano_nerf_amd as pn
+    g, s = golden("pano_full_" + case), golden("stages_" + case)
+    N = s["t_det"].shape[1] - 1
+    rays, env = to_dev(rays_of(s)), to_dev(env_of(golden))
+    model = make_pano(N)
+    with torch.no_grad():
+        outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    assert isinstance(outs, list) and len(outs) == 2 and all(len(t) == 9 for t in outs)
+    assert outs[1][1].shape == (rays.origins.shape[0],)
+    check_tuple(outs, g, "val", NAMES9, g64=g)
+    model.noise_override = dict(t_rand=torch.from_numpy(g["train_t_rand"]), u_rand=torch.from_numpy(g["train_u_rand"]),
+                                env_rand=torch.from_numpy(g["train_env_rand"]))
+    outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    check_tuple(outs, g, "train", NAMES9)
+    loss, _ = pn.pano_loss(outs, rays.lossmult, torch.from_numpy(s["rgbs"]).to(dev()))
+    assert abs(float(loss) - float(g["train/loss"])) < 1e-4 * abs(float(g["train/loss"]))
+    loss.backward()
+    check_grads(model, g, "train")
+    assert model.mlp.last_flat_grad is not None and model.mlp.is_flat()
+    # None-slot contract with surface / orientation off, white background on
+    model.noise_override = None
+    with torch.no_grad():
+        outs2 = model(rays=rays, env_rays=env, randomized=False, white_bkgd=True, enable_surf=False, use_ort_loss=False)
+    assert [i for i, v in enumerate(outs2[1]) if v is None] == list(g["nosurf/none_slots"])
+    assert rel_err(outs2[1][0].cpu(), g["nosurf/l1/comp_rgb"]) < 1e-4
+    assert all(v is None for v in outs2[0][2:])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mip_forward_loss_grads(golden, case):
+    import pano_nerf_amd as pn
+    g, s = golden("mip_full_" + case), golden("stages_" + case)
+    N = s["t_det"].shape[1] - 1
+    rays = to_dev(rays_of(s))
+    model = make_pano(N, nc=1)
+    names = ("comp_rgb", "distance", "ort_loss", "normal")
+    for mode, use_ort in (("val", True), ("valno", False)):
+        with torch.no_grad():
+            outs = model(rays=rays, randomized=False, white_bkgd=False, use_ort_loss=use_ort)
+        assert all(len(t) == 4 for t in outs)
+        check_tuple(outs, g, mode, names)
+    for mode, use_ort in (("train", False), ("trainort", True)):
+        model.noise_override = dict(t_rand=torch.from_numpy(g[mode + "_t_rand"]),
+                                    u_rand=torch.from_numpy(g[mode + "_u_rand"]))
+        for p in model.mlp.parameters():
+            p.grad = None
+        outs = model(rays=rays, randomized=True, white_bkgd=False, use_ort_loss=use_ort)
+        check_tuple(outs, g, mode, names)
+        loss, _ = pn.mip_loss(outs, rays.lossmult, torch.from_numpy(s["rgbs"]).to(dev()), use_ort=use_ort)
+        assert abs(float(loss) - float(g[mode + "/loss"])) < 1e-4 * abs(float(g[mode + "/loss"]))
+        loss.backward()
+        check_grads(model, g, mode)
+
+
+def test_render_image_chunks(golden):
+    """render_image contract (systems/panonerf_system.py:133-192): chunk, render, concatenate."""
+    import pano_nerf_amd as pn
+    g = golden("render_image_8x16")
+    rg = golden("raygen_8x16")
+    rays = pn.generate_pano_rays(8, 16, rg["c2ws"][0])
+    env = pn.generate_lit_rays(10, pn.rays.pano_pixel_radius(rays))
+    img_rays = pn.Rays(*[x.view(1, 8, 16, -1) for x in rays])
+    chunks, _ = pn.rearrange_render_image(img_rays, 32)
+    assert len(chunks) == int(g["n_chunks"])
+    model = make_pano(32)
+    keep = {k: [] for k in ("coarse_rgb", "fine_rgb", "coarse_dep", "fine_dep", "normal", "albedo", "surface_rgb",
+                            "shading")}
+    with torch.no_grad():
+        for ch in chunks:
+            (c_rgb, c_dep, *_), (f_rgb, f_dep, _, f_nor, alb, _, sf, _, sd) = model(
+                rays=ch, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+            for k, v in zip(keep, (c_rgb, f_rgb, c_dep, f_dep, f_nor, alb, sf, sd)):
+                keep[k].append(v)
+    for k, v in keep.items():
+        img = torch.cat(v, 0).view(1, 8, 16, -1).permute(0, 3, 1, 2).cpu().numpy()
+        e = rel_err(img, g[k])
+        if k in ("normal", "surface_rgb", "shading"):
+            assert e < 5e-2, (k, e)
+            assert float(np.median(np.abs(img - g[k]) / (np.abs(g[k]) + 1e-6))) < 1e-4, k
+        else:
+            assert e < 1e-4, (k, e)
+
+
+def test_bench_size_properties():
+    """At the bench configuration (B=512, N=128) the oracle is too slow for a full compare; check
+    size-independent properties: weights are a sub-probability, compositing is linear in colour,
+    determinism, unit normals, gradient finite and shard-additive."""
+    import pano_nerf_amd as pn
+    torch.manual_seed(0)
+    B, N = 512, 128
+    flat, rgbs, radius, _ = orc.synthetic_scene(16, 32, 3, seed=4)
+    idx = torch.randint(0, flat.origins.shape[0], (B,), generator=torch.Generator().manual_seed(4))
+    rays = to_dev(pn.Rays(*[x[idx] for x in flat]))
+    gt = rgbs[idx].to(dev())
+    env = pn.generate_lit_rays(10, radius)
+    model = make_pano(N)
+    S = N + 1
+    gen = torch.Generator().manual_seed(1)
+    model.noise_override = dict(t_rand=torch.rand(B, S, generator=gen),
+                                u_rand=torch.rand(B, S, generator=gen) * (1.0 / S - 1.2e-7),
+                                env_rand=torch.rand(1, 11, generator=gen))
+    outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    loss, terms = pn.pano_loss(outs, rays.lossmult, gt)
+    loss.backward()
+    full = model.mlp.last_flat_grad.clone()
+    assert torch.isfinite(full).all() and float(full.abs().max()) > 0
+    (c0, d0, *_), (c1, d1, ort, nrm, alb, _, sf, dif, shd) = outs
+    assert torch.allclose(nrm.norm(dim=-1), torch.ones(B, device=dev()), atol=1e-4)
+    assert float(alb.min()) >= 0.03 - 1e-6 and float(alb.max()) <= 0.80 + 1e-6
+    assert bool((d1 >= 0).all()) and bool((d1 <= 10).all())
+    assert torch.equal(sf, dif)
+    # determinism: same inputs, same bits
+    outs_b = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    assert torch.equal(outs_b[1][0], c1) and torch.equal(outs_b[1][6], sf)
+    # shard additivity: the mean-loss gradient of the full batch = average of the two half-batch gradients
+    halves = []
+    for lo, hi in ((0, B // 2), (B // 2, B)):
+        sub = pn.Rays(*[x[lo:hi] for x in rays])
+        model.noise_override = dict(t_rand=model.noise_override["t_rand"], u_rand=model.noise_override["u_rand"],
+                                    env_rand=model.noise_override["env_rand"])
+        ov = model.noise_override
+        model.noise_override = dict(t_rand=ov["t_rand"][lo:hi], u_rand=ov["u_rand"][lo:hi], env_rand=ov["env_rand"])
+        for p in model.mlp.parameters():
+            p.grad = None
+        o2 = model(rays=sub, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+        l2, _ = pn.pano_loss(o2, sub.lossmult, gt[lo:hi])
+        l2.backward()
+        halves.append(model.mlp.last_flat_grad.clone())
+        model.noise_override = ov
+    avg = 0.5 * (halves[0] + halves[1])
+    assert float((avg - full).norm() / full.norm()) < 1e-4
+
+
+def test_state_dict_and_errors():
+    import pano_nerf_amd as pn
+    m = pn.PanoMipNeRF(num_samples=8, rgb_activation="softplus", mlp_num_density_channels=5)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "mlp.layers.0.0.weight" and "mlp.view_layers.0.0.bias" in keys and len(keys) == 24
+    assert sum(p.numel() for p in m.mlp.parameters()) == 613768
+    with pytest.raises(NotImplementedError):
+        pn.PanoMipNeRF(rgb_activation="sigmoid")
+    with pytest.raises(NotImplementedError):
+        pn.MipNeRF(rgb_activation="softplus", ray_shape="cylinder")
+    rays = pn.Rays(*[torch.zeros(4, d) for d in (3, 3, 3, 1, 1, 1, 1, 1)])
+    with pytest.raises(RuntimeError, match="no CPU"):
+        pn.MipNeRF(num_samples=8, rgb_activation="softplus")(rays=rays, randomized=False, white_bkgd=False,
+                                                             use_ort_loss=False)

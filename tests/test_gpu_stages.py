@@ -1,0 +1,349 @@
+"""GPU parity, stage by stage: every C-ABI entry point against the oracle / the golden vectors captured
+from the reference, on the same seeded inputs.  Tolerance: 1e-4 relative to the tensor scale (fp32),
+as BASELINE.json's north_star states; index/layout outputs exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import pano_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CASES = ["B64_N32", "B16_N128"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pano_nerf_amd import _lib
+    return _lib
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def G(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32).contiguous().to(dev())
+
+
+def E(*shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev())
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def C(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu()
+
+
+def rays_of(g):
+    return orc.Rays(*[torch.from_numpy(g["ray_" + k]) for k in orc.Rays._fields])
+
+
+def test_raygen(lib, golden):
+    import pano_nerf_amd as pn
+    g = golden("raygen_8x16")
+    for cam in range(g["c2ws"].shape[0]):
+        rays = pn.generate_pano_rays(8, 16, g["c2ws"][cam])
+        for k in orc.Rays._fields:
+            got = C(getattr(rays, k)).numpy().reshape(g[k][cam].shape)
+            np.testing.assert_allclose(got, g[k][cam], rtol=2e-6, atol=2e-7, err_msg=f"{k} cam{cam}")
+    env = pn.generate_lit_rays(10, float(g["radius"]))
+    for k in orc.Rays._fields:
+        t = getattr(env, k)
+        assert t.dtype == torch.float16
+        np.testing.assert_array_equal(C(t).numpy(), g["env_" + k], err_msg=k)
+    g2 = golden("raygen_64x128")
+    rays = pn.generate_pano_rays(64, 128, g2["c2ws"][0])
+    for k in orc.Rays._fields:
+        got = C(getattr(rays, k)).numpy().reshape(64, 128, -1)[::7, ::9]
+        np.testing.assert_allclose(got, g2[k], rtol=2e-6, atol=2e-7, err_msg=k)
+    assert abs(pn.rays.pano_pixel_radius(rays) - float(g2["radius"])) < 1e-7 * 10
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_sampling(lib, golden, case):
+    g = golden("stages_" + case)
+    B, S = g["t_det"].shape
+    N = S - 1
+    o, d = G(g["ray_origins"]), G(g["ray_directions"])
+    rad, nr, fr = G(g["ray_radii"]).view(-1), G(g["ray_near"]).view(-1), G(g["ray_far"]).view(-1)
+    for rnd, kt, km, kc in ((None, "t_det", "mean_det", "cov_det"), (G(g["t_rand"]), "t_rnd", "mean_rnd", "cov_rnd")):
+        t, m, c = E(B, S), E(B * N, 3), E(B * N, 3)
+        lib.call("pn_sample_coarse", B, N, o.data_ptr(), d.data_ptr(), rad.data_ptr(), nr.data_ptr(), fr.data_ptr(),
+                 lib.ptr(rnd), t.data_ptr(), m.data_ptr(), c.data_ptr(), st())
+        assert rel_err(C(t), g[kt]) < 1e-6, kt
+        assert rel_err(C(m).view(B, N, 3), g[km]) < 1e-6, km
+        assert rel_err(C(c).view(B, N, 3), g[kc]) < 1e-5, kc
+    # resample: deterministic, randomized, all-zero weights
+    t_in, w = G(g["t_rnd"]), G(g["weights"])
+    for u, wt, pad, kt in ((None, w, 0.01, "t_resample_det"), (G(g["u_rand"]), w, 0.01, "t_resample_rnd"),
+                           (None, torch.zeros_like(w), 0.0, "t_resample_zero")):
+        t, m, c = E(B, S), E(B * N, 3), E(B * N, 3)
+        lib.call("pn_resample", B, N, t_in.data_ptr(), wt.data_ptr(), pad, lib.ptr(u), o.data_ptr(), d.data_ptr(),
+                 rad.data_ptr(), t.data_ptr(), m.data_ptr(), c.data_ptr(), st())
+        tt = C(t)
+        assert rel_err(tt, g[kt]) < 2e-6, (kt, rel_err(tt, g[kt]))
+        assert bool((tt[:, 1:] >= tt[:, :-1]).all()), "resampled t must be sorted"
+        if kt == "t_resample_det":
+            assert rel_err(C(m).view(B, N, 3), g["mean_resample_det"]) < 2e-6
+            assert rel_err(C(c).view(B, N, 3), g["cov_resample_det"]) < 1e-4
+    # env light rays
+    env = golden("raygen_8x16")
+    ed, er = G(env["env_directions"]), G(env["env_radii"]).view(-1)
+    en, ef = G(env["env_near"]).view(-1), G(env["env_far"]).view(-1)
+    D, Ne = 10, 10
+    dist = G(g["distance"])
+    t, m, c = E(B * D, Ne + 1), E(B * D * Ne, 3), E(B * D * Ne, 3)
+    lib.call("pn_sample_env", B, D, Ne, o.data_ptr(), d.data_ptr(), dist.data_ptr(), ed.data_ptr(), er.data_ptr(),
+             en.data_ptr(), ef.data_ptr(), G(g["env_rand"]).view(-1).data_ptr(), t.data_ptr(), m.data_ptr(),
+             c.data_ptr(), st())
+    assert rel_err(C(t)[:40], g["lit_t"]) < 1e-6
+    assert rel_err(C(m).view(B * D, Ne, 3)[:40], g["lit_mean"]) < 1e-6
+    assert rel_err(C(c).view(B * D, Ne, 3)[:40], g["lit_cov"]) < 1e-5
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_encodings(lib, golden, case):
+    g = golden("stages_" + case)
+    B, N = g["mean_rnd"].shape[:2]
+    M = B * N
+    m, c = G(g["mean_rnd"]).view(M, 3), G(g["cov_rnd"]).view(M, 3)
+    enc = E(int(lib.load().pn_pad_rows(M)), 96)
+    lib.call("pn_ipe_encode", M, m.data_ptr(), c.data_ptr(), enc.data_ptr(), st())
+    got = C(enc)[:M].view(B, N, 96)
+    ref = orc.integrated_pos_enc(torch.from_numpy(g["mean_rnd"]), torch.from_numpy(g["cov_rnd"]), 0, 16)
+    assert rel_err(got[:4], g["enc_head"]) < 2e-6
+    assert rel_err(got, ref) < 2e-6
+    ve = E(B, 27)
+    lib.call("pn_pos_enc_view", B, G(g["ray_viewdirs"]).data_ptr(), ve.data_ptr(), st())
+    assert rel_err(C(ve), g["viewenc"]) < 2e-6
+
+
+def test_gemm_nt_tn(lib):
+    gen = torch.Generator().manual_seed(0)
+    for (M, N, K) in ((300, 256, 96), (1000, 128, 256), (129, 96, 352), (64, 256, 8)):
+        A = torch.randn(M, K, generator=gen)
+        Bt = torch.randn(N, K, generator=gen)  # asymmetric operands catch transposed maps
+        bias = torch.randn(N, generator=gen)
+        gate = torch.randn(M, N, generator=gen)
+        ref = (A.double() @ Bt.double().T + bias.double())
+        ref = torch.where(gate > 0, torch.relu(ref), torch.zeros_like(ref)).float()
+        Cd = torch.full((M, N), 7.0, device=dev())
+        lib.call("pn_gemm_nt", M, N, K, G(A).data_ptr(), K, G(Bt).data_ptr(), K, Cd.data_ptr(), N,
+                 G(bias).data_ptr(), G(gate).data_ptr(), N, 1 | 2 | 4, st())
+        assert rel_err(C(Cd), ref) < 2e-6, (M, N, K, rel_err(C(Cd), ref))
+    for (M, N1, N2) in ((1000, 256, 256), (333, 128, 32), (5000, 256, 96), (31, 256, 256)):
+        X = torch.randn(M, N1, generator=gen)
+        Y = torch.randn(M, N2, generator=gen)
+        ref = (X.double().T @ Y.double()).float()
+        work = E(int(lib.load().pn_gemm_tn_work_floats(M, N1, N2)))
+        Cd = torch.ones(N1, N2, device=dev())
+        lib.call("pn_gemm_tn", M, N1, N2, G(X).data_ptr(), N1, G(Y).data_ptr(), N2, Cd.data_ptr(), N2, 1,
+                 work.data_ptr(), st())
+        assert rel_err(C(Cd) - 1.0, ref) < 5e-6, (M, N1, N2, rel_err(C(Cd) - 1.0, ref))
+    # identity A against an asymmetric B: the output must be B^T exactly (layout check)
+    K = 256
+    A = torch.eye(K)
+    Bt = torch.arange(128 * K, dtype=torch.float32).view(128, K) / 1024.0
+    Cd = E(K, 128)
+    lib.call("pn_gemm_nt", K, 128, K, G(A).data_ptr(), K, G(Bt).data_ptr(), K, Cd.data_ptr(), 128, None, None, 0, 0,
+             st())
+    assert torch.equal(C(Cd), Bt.T.contiguous())
+    # bad arguments are refused, not launched
+    assert lib.load().pn_gemm_nt(0, 128, 256, None, 256, None, 256, None, 128, None, None, 0, 0, None) < 0
+    assert lib.load().pn_gemm_nt(8, 128, 255, Cd.data_ptr(), 255, Cd.data_ptr(), 255, Cd.data_ptr(), 128, None, None,
+                                 0, 0, None) < 0
+
+
+def _mlp_eval(lib, p_flat, wpack, nc, mean, cov, viewdirs, rows_per_ray):
+    M = mean.shape[0]
+    Mp = int(lib.load().pn_pad_rows(M))
+    R = viewdirs.shape[0]
+    buf = dict(enc=E(Mp, 96), viewenc=E(R, 27), viewbias=E(R, 128), acts=E(10, Mp, 256), raw_rgb=E(M, 3),
+               raw_den=E(M, nc))
+    lib.call("pn_mlp_forward", M, rows_per_ray, R, nc, p_flat.data_ptr(), wpack.data_ptr(), mean.data_ptr(),
+             cov.data_ptr(), viewdirs.data_ptr(), buf["enc"].data_ptr(), buf["viewenc"].data_ptr(),
+             buf["viewbias"].data_ptr(), buf["acts"].data_ptr(), buf["raw_rgb"].data_ptr(), buf["raw_den"].data_ptr(),
+             st())
+    return buf
+
+
+def _flat_params(lib, params, nc):
+    from pano_nerf_amd.mlp import ORDER, param_layout
+    off, total = param_layout(nc)
+    flat = torch.zeros(total)
+    for k in ORDER:
+        flat[off[k]:off[k] + params[k].numel()] = params[k].reshape(-1)
+    flat = flat.to(dev())
+    wpack = E(int(lib.load().pn_wpack_floats(nc)))
+    lib.call("pn_pack_weights", flat.data_ptr(), nc, wpack.data_ptr(), st())
+    return flat, wpack, off, total
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mlp_forward_and_density_grad(lib, golden, case):
+    g = golden("stages_" + case)
+    B, N = g["mean_rnd"].shape[:2]
+    M = B * N
+    params = orc.init_params(4, 5)
+    flat, wpack, _, _ = _flat_params(lib, params, 5)
+    mean, cov, vd = G(g["mean_rnd"]).view(M, 3), G(g["cov_rnd"]).view(M, 3), G(g["ray_viewdirs"])
+    buf = _mlp_eval(lib, flat, wpack, 5, mean, cov, vd, N)
+    assert rel_err(C(buf["raw_rgb"]).view(B, N, 3), g["raw_rgb"]) < TOL
+    assert rel_err(C(buf["raw_den"]).view(B, N, 5), g["raw_den"]) < TOL
+    # density gradient vs autograd of the oracle (fp64 oracle: the fp32 one is itself ill-conditioned)
+    Mp = int(lib.load().pn_pad_rows(M))
+    rs, scratch, gm = E(8, Mp, 256), E(Mp, 96), E(M, 3)
+    lib.call("pn_density_grad", M, 5, -1.0, flat.data_ptr(), wpack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
+             buf["acts"].data_ptr(), buf["raw_den"].data_ptr(), rs.data_ptr(), scratch.data_ptr(), gm.data_ptr(), st())
+    got = C(gm).view(B, N, 3)
+    p64 = {k: v.double() for k, v in params.items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        m64 = torch.from_numpy(g["mean_rnd"]).double().requires_grad_(True)
+        _, sig, _ = orc.radiance_field(p64, m64, torch.from_numpy(g["cov_rnd"]).double(),
+                                       torch.from_numpy(g["ray_viewdirs"]).double())
+        (ref,) = torch.autograd.grad(sig.sum(), m64)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    err = (got.double() - ref).abs()
+    scale = ref.abs().max()
+    # fp32 error of a 2^15-gain Jacobian: bounded relative to the tensor scale, tight in the median
+    assert float(err.max() / scale) < 5e-3, float(err.max() / scale)
+    assert float(err.median() / ref.abs().median()) < 1e-4, float(err.median() / ref.abs().median())
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("white", [False, True])
+def test_composite_forward_backward(lib, golden, case, white):
+    g = golden("stages_" + case)
+    B, N = g["weights"].shape
+    rr, rd, t, d = G(g["raw_rgb"]).view(-1, 3), G(g["raw_den"]).view(-1, 5), G(g["t_rnd"]), G(g["ray_directions"])
+    comp, dist, acc, w = E(B, 3), E(B), E(B), E(B, N)
+    lib.call("pn_composite_forward", B, N, 5, -1.0, 0.0, int(white), rr.data_ptr(), rd.data_ptr(), t.data_ptr(),
+             d.data_ptr(), B, comp.data_ptr(), dist.data_ptr(), acc.data_ptr(), w.data_ptr(), st())
+    assert rel_err(C(comp), g["comp_rgb_white" if white else "comp_rgb"]) < 1e-5
+    assert rel_err(C(dist), g["distance"]) < 1e-5
+    assert rel_err(C(acc), g["acc"]) < 1e-5
+    assert rel_err(C(w), g["weights"]) < 1e-5
+    # adjoint vs oracle autograd
+    gen = torch.Generator().manual_seed(3)
+    gc, gd, gw = torch.randn(B, 3, generator=gen), torch.randn(B, generator=gen), torch.randn(B, N, generator=gen)
+    raw_rgb = torch.from_numpy(g["raw_rgb"]).clone().requires_grad_(True)
+    raw_den = torch.from_numpy(g["raw_den"]).clone().requires_grad_(True)
+    sp = torch.nn.functional.softplus
+    c_, d_, a_, w_ = orc.volumetric_rendering(sp(raw_rgb), sp(raw_den[..., :1] - 1), torch.from_numpy(g["t_rnd"]),
+                                              torch.from_numpy(g["ray_directions"]), white)
+    ((c_ * gc).sum() + (d_ * gd).sum() + (w_ * gw).sum()).backward()
+    drr, drd = torch.zeros(B * N, 3, device=dev()), torch.zeros(B * N, 5, device=dev())
+    lib.call("pn_composite_backward", B, N, 5, -1.0, 0.0, int(white), rr.data_ptr(), rd.data_ptr(), t.data_ptr(),
+             d.data_ptr(), B, G(gc).data_ptr(), G(gd).data_ptr(), G(gw).data_ptr(), drr.data_ptr(), drd.data_ptr(), st())
+    assert rel_err(C(drr).view(B, N, 3), raw_rgb.grad) < TOL
+    assert rel_err(C(drd).view(B, N, 5)[..., 0], raw_den.grad[..., 0]) < TOL
+    assert float(C(drd).view(B, N, 5)[..., 1:].abs().max()) == 0.0
+
+
+def test_composite_short_env_rays(lib):
+    """10-sample light rays use the 16-lane groups; directions are shared modulo D."""
+    gen = torch.Generator().manual_seed(5)
+    R, N, D = 70, 10, 10
+    rr, rd = torch.randn(R, N, 3, generator=gen), torch.randn(R, N, 5, generator=gen) + 1
+    t = torch.sort(torch.rand(R, N + 1, generator=gen) * 10, -1)[0]
+    dirs = torch.randn(D, 3, generator=gen)
+    sp = torch.nn.functional.softplus
+    full_d = dirs[torch.arange(R) % D]
+    c_, d_, a_, w_ = orc.volumetric_rendering(sp(rr), sp(rd[..., :1] - 1), t, full_d, False)
+    comp, dist, acc, w = E(R, 3), E(R), E(R), E(R, N)
+    lib.call("pn_composite_forward", R, N, 5, -1.0, 0.0, 0, G(rr).view(-1, 3).data_ptr(), G(rd).view(-1, 5).data_ptr(),
+             G(t).data_ptr(), G(dirs).data_ptr(), D, comp.data_ptr(), dist.data_ptr(), acc.data_ptr(), w.data_ptr(),
+             st())
+    for a, b in ((comp, c_), (dist, d_), (acc, a_), (w, w_)):
+        assert rel_err(C(a), b) < 1e-5
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gather_surface_loss(lib, golden, case):
+    g = golden("stages_" + case)
+    B, N = g["weights"].shape
+    gen = torch.Generator().manual_seed(9)
+    gm = torch.randn(B, N, 3, generator=gen)
+    w = torch.from_numpy(g["weights"]).clone()
+    rd = torch.from_numpy(g["raw_den"]).clone()
+    dirs = torch.from_numpy(g["ray_directions"])
+    # oracle
+    gm_r, w_r, rd_r = gm.clone().requires_grad_(True), w.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+    nw = w_r[..., None] / w_r.sum(-1).view(-1, 1, 1)
+    normals = torch.nn.functional.normalize(-gm_r, dim=-1)
+    normal = torch.nn.functional.normalize((nw * normals).sum(1), dim=-1)
+    ort_ray = (nw * torch.relu((normals * dirs[:, None, :]).sum(-1, keepdim=True)) ** 2).sum(1)[:, 0]
+    alb = (nw * (torch.sigmoid(rd_r[..., 1:-1]) * 0.77 + 0.03)).sum(1)
+    nrm_d, ort_d, alb_d = E(B, 3), E(B), E(B, 3)
+    args = (G(gm).view(-1, 3), G(w), G(rd).view(-1, 5), G(dirs))
+    lib.call("pn_surf_gather_forward", B, N, 5, *[a.data_ptr() for a in args], nrm_d.data_ptr(), ort_d.data_ptr(),
+             alb_d.data_ptr(), st())
+    assert rel_err(C(nrm_d), normal.detach()) < 1e-5
+    assert rel_err(C(ort_d), ort_ray.detach()) < 1e-5
+    assert rel_err(C(alb_d), alb.detach()) < 1e-5
+    gn, go, ga = torch.randn(B, 3, generator=gen), torch.randn(B, generator=gen), torch.randn(B, 3, generator=gen)
+    ((normal * gn).sum() + (ort_ray * go).sum() + (alb * ga).sum()).backward()
+    dw, v, drd = E(B, N), E(B * N, 3), torch.zeros(B * N, 5, device=dev())
+    lib.call("pn_surf_gather_backward", B, N, 5, *[a.data_ptr() for a in args], G(gn).data_ptr(), G(go).data_ptr(),
+             G(ga).data_ptr(), dw.data_ptr(), v.data_ptr(), drd.data_ptr(), st())
+    assert rel_err(C(dw), w_r.grad) < TOL
+    assert rel_err(C(v).view(B, N, 3), gm_r.grad) < TOL
+    assert rel_err(C(drd).view(B, N, 5), rd_r.grad) < TOL
+    # surface (a14)
+    env = golden("raygen_8x16")
+    ed, om = torch.from_numpy(env["env_directions"]).float(), torch.from_numpy(env["env_lossmult"]).float()
+    e_r = torch.from_numpy(g["sr_env"]).clone().requires_grad_(True)
+    a_r = torch.from_numpy(g["sr_albedo"]).clone().requires_grad_(True)
+    n_r = torch.from_numpy(g["sr_normal"]).clone().requires_grad_(True)
+    srgb, dif, shd = orc.surface_rendering(e_r, a_r, n_r, ed[None].expand(B, 10, 3), om)
+    dif_d, shd_d = E(B, 3), E(B, 3)
+    sargs = (G(g["sr_env"]), G(g["sr_albedo"]), G(g["sr_normal"]), G(ed), G(om).view(-1))
+    lib.call("pn_surface_forward", B, 10, *[a.data_ptr() for a in sargs], dif_d.data_ptr(), shd_d.data_ptr(), st())
+    assert rel_err(C(dif_d), g["sr_diffuse"]) < 1e-5 and rel_err(C(shd_d), g["sr_shading"]) < 1e-5
+    gd_, gs_ = torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen)
+    ((dif * gd_).sum() + (shd * gs_).sum()).backward()
+    de, da, dn = E(B, 10, 3), E(B, 3), E(B, 3)
+    lib.call("pn_surface_backward", B, 10, *[a.data_ptr() for a in sargs], G(gd_).data_ptr(), G(gs_).data_ptr(),
+             de.data_ptr(), da.data_ptr(), dn.data_ptr(), st())
+    assert rel_err(C(de), e_r.grad) < TOL and rel_err(C(da), a_r.grad) < TOL and rel_err(C(dn), n_r.grad) < TOL
+    # tone-mapped loss (a15) forward + gradients
+    from pano_nerf_amd.loss import _ToneLossFn
+    rgbs, mask = torch.from_numpy(g["rgbs"]), torch.from_numpy(g["ray_lossmult"])
+    xs = [torch.rand(B, 3, generator=gen) * 2 for _ in range(4)]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    outs = [(xr[0],), (xr[1], None, None, None, xr[3], None, xr[2], None, None)]
+    ref = orc.pano_loss(outs, mask, rgbs)
+    ref.backward()
+    xd = [x.clone().to(dev()).requires_grad_(True) for x in xs]
+    total, terms = _ToneLossFn.apply((0.1, 1.0, 0.1), rgbs.to(dev()), mask.to(dev()), xd[0], xd[1], xd[2], xd[3])
+    total.backward()
+    assert abs(float(total) - float(ref)) < 1e-5 * abs(float(ref))
+    for a, b in zip(xd, xr):
+        assert rel_err(C(a.grad), b.grad) < TOL
+    assert rel_err(orc.hdr_to_ldr(torch.from_numpy(g["tm_in"])), g["tm_out"]) < 1e-6
+
+
+def test_adam_matches_torch(lib):
+    import pano_nerf_amd as pn
+    torch.manual_seed(0)
+    m = pn.MipNeRF(num_samples=8, rgb_activation="softplus", mlp_num_density_channels=1).to(dev())
+    ref_p = m.mlp.flat_params().detach().clone().cpu().requires_grad_(True)
+    opt_ref = torch.optim.Adam([ref_p], lr=2e-4)
+    opt = pn.FlatAdam(m.mlp, lr=2e-4)
+    for step in range(3):
+        gr = torch.randn(ref_p.numel(), generator=torch.Generator().manual_seed(step))
+        ref_p.grad = gr.clone()
+        opt_ref.step()
+        opt.step(flat_grad=gr.to(dev()))
+    assert rel_err(C(m.mlp.flat_params()), ref_p.detach()) < 1e-6
+    assert m.mlp.is_flat()
