@@ -101,8 +101,9 @@ def test_sampling(lib, golden, case):
     D, Ne = 10, 10
     dist = G(g["distance"])
     t, m, c = E(B * D, Ne + 1), E(B * D * Ne, 3), E(B * D * Ne, 3)
+    erand = G(g["env_rand"]).view(-1)
     lib.call("pn_sample_env", B, D, Ne, o.data_ptr(), d.data_ptr(), dist.data_ptr(), ed.data_ptr(), er.data_ptr(),
-             en.data_ptr(), ef.data_ptr(), G(g["env_rand"]).view(-1).data_ptr(), t.data_ptr(), m.data_ptr(),
+             en.data_ptr(), ef.data_ptr(), erand.data_ptr(), t.data_ptr(), m.data_ptr(),
              c.data_ptr(), st())
     assert rel_err(C(t)[:40], g["lit_t"]) < 1e-6
     assert rel_err(C(m).view(B * D, Ne, 3)[:40], g["lit_mean"]) < 1e-6
@@ -122,7 +123,8 @@ def test_encodings(lib, golden, case):
     assert rel_err(got[:4], g["enc_head"]) < 2e-6
     assert rel_err(got, ref) < 2e-6
     ve = E(B, 27)
-    lib.call("pn_pos_enc_view", B, G(g["ray_viewdirs"]).data_ptr(), ve.data_ptr(), st())
+    dvd = G(g["ray_viewdirs"])
+    lib.call("pn_pos_enc_view", B, dvd.data_ptr(), ve.data_ptr(), st())
     assert rel_err(C(ve), g["viewenc"]) < 2e-6
 
 
@@ -136,8 +138,9 @@ def test_gemm_nt_tn(lib):
         ref = (A.double() @ Bt.double().T + bias.double())
         ref = torch.where(gate > 0, torch.relu(ref), torch.zeros_like(ref)).float()
         Cd = torch.full((M, N), 7.0, device=dev())
-        lib.call("pn_gemm_nt", M, N, K, G(A).data_ptr(), K, G(Bt).data_ptr(), K, Cd.data_ptr(), N,
-                 G(bias).data_ptr(), G(gate).data_ptr(), N, 1 | 2 | 4, st())
+        dA, dB, dbias, dgate = G(A), G(Bt), G(bias), G(gate)  # keep alive: data_ptr() of a temporary dangles
+        lib.call("pn_gemm_nt", M, N, K, dA.data_ptr(), K, dB.data_ptr(), K, Cd.data_ptr(), N,
+                 dbias.data_ptr(), dgate.data_ptr(), N, 1 | 2 | 4, st())
         assert rel_err(C(Cd), ref) < 2e-6, (M, N, K, rel_err(C(Cd), ref))
     for (M, N1, N2) in ((1000, 256, 256), (333, 128, 32), (5000, 256, 96), (31, 256, 256)):
         X = torch.randn(M, N1, generator=gen)
@@ -145,7 +148,8 @@ def test_gemm_nt_tn(lib):
         ref = (X.double().T @ Y.double()).float()
         work = E(int(lib.load().pn_gemm_tn_work_floats(M, N1, N2)))
         Cd = torch.ones(N1, N2, device=dev())
-        lib.call("pn_gemm_tn", M, N1, N2, G(X).data_ptr(), N1, G(Y).data_ptr(), N2, Cd.data_ptr(), N2, 1,
+        dX, dY = G(X), G(Y)
+        lib.call("pn_gemm_tn", M, N1, N2, dX.data_ptr(), N1, dY.data_ptr(), N2, Cd.data_ptr(), N2, 1,
                  work.data_ptr(), st())
         assert rel_err(C(Cd) - 1.0, ref) < 5e-6, (M, N1, N2, rel_err(C(Cd) - 1.0, ref))
     # identity A against an asymmetric B: the output must be B^T exactly (layout check)
@@ -153,7 +157,8 @@ def test_gemm_nt_tn(lib):
     A = torch.eye(K)
     Bt = torch.arange(128 * K, dtype=torch.float32).view(128, K) / 1024.0
     Cd = E(K, 128)
-    lib.call("pn_gemm_nt", K, 128, K, G(A).data_ptr(), K, G(Bt).data_ptr(), K, Cd.data_ptr(), 128, None, None, 0, 0,
+    dA, dB = G(A), G(Bt)
+    lib.call("pn_gemm_nt", K, 128, K, dA.data_ptr(), K, dB.data_ptr(), K, Cd.data_ptr(), 128, None, None, 0, 0,
              st())
     assert torch.equal(C(Cd), Bt.T.contiguous())
     # bad arguments are refused, not launched
@@ -243,8 +248,9 @@ def test_composite_forward_backward(lib, golden, case, white):
                                               torch.from_numpy(g["ray_directions"]), white)
     ((c_ * gc).sum() + (d_ * gd).sum() + (w_ * gw).sum()).backward()
     drr, drd = torch.zeros(B * N, 3, device=dev()), torch.zeros(B * N, 5, device=dev())
+    dgc, dgd, dgw = G(gc), G(gd), G(gw)
     lib.call("pn_composite_backward", B, N, 5, -1.0, 0.0, int(white), rr.data_ptr(), rd.data_ptr(), t.data_ptr(),
-             d.data_ptr(), B, G(gc).data_ptr(), G(gd).data_ptr(), G(gw).data_ptr(), drr.data_ptr(), drd.data_ptr(), st())
+             d.data_ptr(), B, dgc.data_ptr(), dgd.data_ptr(), dgw.data_ptr(), drr.data_ptr(), drd.data_ptr(), st())
     assert rel_err(C(drr).view(B, N, 3), raw_rgb.grad) < TOL
     assert rel_err(C(drd).view(B, N, 5)[..., 0], raw_den.grad[..., 0]) < TOL
     assert float(C(drd).view(B, N, 5)[..., 1:].abs().max()) == 0.0
@@ -261,8 +267,9 @@ def test_composite_short_env_rays(lib):
     full_d = dirs[torch.arange(R) % D]
     c_, d_, a_, w_ = orc.volumetric_rendering(sp(rr), sp(rd[..., :1] - 1), t, full_d, False)
     comp, dist, acc, w = E(R, 3), E(R), E(R), E(R, N)
-    lib.call("pn_composite_forward", R, N, 5, -1.0, 0.0, 0, G(rr).view(-1, 3).data_ptr(), G(rd).view(-1, 5).data_ptr(),
-             G(t).data_ptr(), G(dirs).data_ptr(), D, comp.data_ptr(), dist.data_ptr(), acc.data_ptr(), w.data_ptr(),
+    drr_, drd_, dt_, ddirs_ = G(rr).view(-1, 3), G(rd).view(-1, 5), G(t), G(dirs)
+    lib.call("pn_composite_forward", R, N, 5, -1.0, 0.0, 0, drr_.data_ptr(), drd_.data_ptr(),
+             dt_.data_ptr(), ddirs_.data_ptr(), D, comp.data_ptr(), dist.data_ptr(), acc.data_ptr(), w.data_ptr(),
              st())
     for a, b in ((comp, c_), (dist, d_), (acc, a_), (w, w_)):
         assert rel_err(C(a), b) < 1e-5
@@ -294,8 +301,9 @@ def test_gather_surface_loss(lib, golden, case):
     gn, go, ga = torch.randn(B, 3, generator=gen), torch.randn(B, generator=gen), torch.randn(B, 3, generator=gen)
     ((normal * gn).sum() + (ort_ray * go).sum() + (alb * ga).sum()).backward()
     dw, v, drd = E(B, N), E(B * N, 3), torch.zeros(B * N, 5, device=dev())
-    lib.call("pn_surf_gather_backward", B, N, 5, *[a.data_ptr() for a in args], G(gn).data_ptr(), G(go).data_ptr(),
-             G(ga).data_ptr(), dw.data_ptr(), v.data_ptr(), drd.data_ptr(), st())
+    dgn, dgo, dga = G(gn), G(go), G(ga)
+    lib.call("pn_surf_gather_backward", B, N, 5, *[a.data_ptr() for a in args], dgn.data_ptr(), dgo.data_ptr(),
+             dga.data_ptr(), dw.data_ptr(), v.data_ptr(), drd.data_ptr(), st())
     assert rel_err(C(dw), w_r.grad) < TOL
     assert rel_err(C(v).view(B, N, 3), gm_r.grad) < TOL
     assert rel_err(C(drd).view(B, N, 5), rd_r.grad) < TOL
@@ -313,7 +321,8 @@ def test_gather_surface_loss(lib, golden, case):
     gd_, gs_ = torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen)
     ((dif * gd_).sum() + (shd * gs_).sum()).backward()
     de, da, dn = E(B, 10, 3), E(B, 3), E(B, 3)
-    lib.call("pn_surface_backward", B, 10, *[a.data_ptr() for a in sargs], G(gd_).data_ptr(), G(gs_).data_ptr(),
+    dgd_, dgs_ = G(gd_), G(gs_)
+    lib.call("pn_surface_backward", B, 10, *[a.data_ptr() for a in sargs], dgd_.data_ptr(), dgs_.data_ptr(),
              de.data_ptr(), da.data_ptr(), dn.data_ptr(), st())
     assert rel_err(C(de), e_r.grad) < TOL and rel_err(C(da), a_r.grad) < TOL and rel_err(C(dn), n_r.grad) < TOL
     # tone-mapped loss (a15) forward + gradients
