@@ -106,9 +106,13 @@ int pn_pos_enc_view(int64_t R, const float* viewdirs, float* viewenc, void* stre
  * gradient re-read them).  enc: [Mpad,96] (written).  viewenc: [view_rows,27] (written),
  * viewbias: [view_rows,128] scratch. */
 #define PN_ACT_SLOTS 10
+/* masks: [PN_MASK_SLOTS][Mpad][PN_MASK_WORDS] u32 — ReLU gates of h0..h7 and the view hidden as bit masks
+ * (written here, read by pn_density_grad / pn_mlp_backward: 32 B/row instead of re-reading 1 KB/row). */
+#define PN_MASK_SLOTS 9
+#define PN_MASK_WORDS 8
 int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, const float* params,
                    const float* wpack, const float* mean, const float* cov, const float* viewdirs, float* enc,
-                   float* viewenc, float* viewbias, float* acts, float* raw_rgb /*[M,3]*/,
+                   float* viewenc, float* viewbias, float* acts, uint32_t* masks, float* raw_rgb /*[M,3]*/,
                    float* raw_density /*[M,nc]*/, void* stream);
 
 /* d sigma / d mean per sample: what vmap(jacrev(compute_graph))[1] keeps
@@ -118,7 +122,8 @@ int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_densi
  * scratch: [Mpad,96].  Output grad_mean [M,3] = + d sigma / d mean (caller negates). */
 int pn_density_grad(int64_t M, int num_density_channels, float density_bias, const float* params,
                     const float* wpack, const float* mean, const float* cov, const float* acts,
-                    const float* raw_density, float* rsweep, float* scratch, float* grad_mean, void* stream);
+                    const uint32_t* masks, const float* raw_density, float* rsweep, float* scratch,
+                    float* grad_mean, void* stream);
 
 /* Backward of pn_mlp_forward (+ optionally of pn_density_grad).  Accumulates (+=) into
  * `grads` (flat block, layout of pn_param_layout).
@@ -131,9 +136,10 @@ int pn_density_grad(int64_t M, int num_density_channels, float density_bias, con
 int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows);
 int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, float density_bias,
                     const float* params, const float* wpack, const float* mean, const float* cov,
-                    const float* enc, const float* viewenc, const float* acts, const float* raw_density,
-                    const float* d_raw_rgb, const float* d_raw_density, const float* rsweep,
-                    const float* v_gradmean, float* d_mean, float* grads, float* work, void* stream);
+                    const float* enc, const float* viewenc, const float* acts, const uint32_t* masks,
+                    const float* raw_density, const float* d_raw_rgb, const float* d_raw_density,
+                    const float* rsweep, const float* v_gradmean, float* d_mean, float* grads, float* work,
+                    void* stream);
 
 /* ---- volumetric rendering ---------------------------------------------------------
  * compute_graph activations (models/pano_mip_nerf.py:273-278) + volumetric_rendering
@@ -205,6 +211,13 @@ int pn_gemm_nt(int64_t M, int N, int K, const float* A, int lda, const float* Bt
 int64_t pn_gemm_tn_work_floats(int64_t M, int N1, int N2);
 int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* Y, int ldy, float* C, int ldc,
                int accumulate, float* work, void* stream);
+
+/* ---- launch timing (bench.py roofline leg; off by default; the one piece of process state) ---
+ * While enabled every GEMM launch is bracketed by HIP events on its own stream.  pn_prof_read waits
+ * for the recorded events and returns, for kernel class cls (0 = k_gemm_nt, 1 = k_gemm_tn), the summed
+ * duration in ms, the launch count and the summed algorithmic FLOPs (2*M*N*K, unpadded). */
+int pn_prof_enable(int on);
+int pn_prof_read(int cls, double* total_ms, int64_t* launches, double* flops);
 
 #ifdef __cplusplus
 }

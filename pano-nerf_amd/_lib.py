@@ -28,10 +28,10 @@ SIGNATURES = {
     "pn_sample_env": ("i", "lii" + "p" * 11 + "p"),
     "pn_ipe_encode": ("i", "lpppp"),
     "pn_pos_enc_view": ("i", "lppp"),
-    "pn_mlp_forward": ("i", "lili" + "p" * 11 + "p"),
-    "pn_density_grad": ("i", "lif" + "p" * 9 + "p"),
+    "pn_mlp_forward": ("i", "lili" + "p" * 12 + "p"),
+    "pn_density_grad": ("i", "lif" + "p" * 10 + "p"),
     "pn_mlp_backward_work_floats": ("l", "ll"),
-    "pn_mlp_backward": ("i", "lilif" + "p" * 15 + "p"),
+    "pn_mlp_backward": ("i", "lilif" + "p" * 16 + "p"),
     "pn_composite_forward": ("i", "liiffi" + "pppp" + "l" + "pppp" + "p"),
     "pn_composite_backward": ("i", "liiffi" + "pppp" + "l" + "ppppp" + "p"),
     "pn_surf_gather_forward": ("i", "lii" + "p" * 7 + "p"),
@@ -44,6 +44,8 @@ SIGNATURES = {
     "pn_gemm_nt": ("i", "liipipipippiip"),
     "pn_gemm_tn_work_floats": ("l", "lii"),
     "pn_gemm_tn": ("i", "liipipipiipp"),
+    "pn_prof_enable": ("i", "i"),
+    "pn_prof_read": ("i", "ippp"),
 }
 
 _lib = None

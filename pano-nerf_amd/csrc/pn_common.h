@@ -20,7 +20,14 @@ struct PnSeg {
     const float* B;   // [N, K] row-major, leading dim ldb   (C = A * B^T)
     int lda, ldb, K;  // K % 4 == 0, lda % 4 == 0, ldb % 4 == 0, 16-byte aligned bases
 };
-enum { PN_EPI_BIAS = 1, PN_EPI_RELU = 2, PN_EPI_GATE = 4, PN_EPI_ROWBIAS = 8, PN_EPI_ADDC = 16 };
+enum {
+    PN_EPI_BIAS = 1, PN_EPI_RELU = 2, PN_EPI_GATE = 4, PN_EPI_ROWBIAS = 8, PN_EPI_ADDC = 16,
+    PN_EPI_GATEBITS = 32,  // gate by the bit mask written by an earlier PN_EPI_MASKOUT launch
+    PN_EPI_MASKOUT = 64,   // write (value > 0) bits, one u32 per (row, 32 columns)
+    PN_EPI_COLSUM = 128    // write per-wave column sums of the stored tile (bias gradients)
+};
+// bit (c*8 + i) of mask word [row][col/32] <-> column 32*(col/32) + 4*i + c   (i = 0..7, c = 0..3)
+// PN_MASK_WORDS (8 u32 per row) / PN_MASK_SLOTS (h0..h7, view hidden) come from panonerf_hip.h
 struct PnGemmNt {
     PnSeg seg[2];
     int nseg;
@@ -36,8 +43,14 @@ struct PnGemmNt {
     int ldadd;
     const float* gate;  // [M, N] gate source (> 0 passes), leading dim ldg
     int ldg;
+    const uint32_t* gate_bits;  // [M, PN_MASK_WORDS]
+    uint32_t* mask_out;         // [M, PN_MASK_WORDS]
+    float* colsum;              // [2 * ceil(M/128), N] per-wave-row column sums (PN_EPI_COLSUM)
     int flags;
 };
+// dst[r*ldd + c] (+)= sum_b src[b*stride + r*src_ld + c]  for r < rows, c < cols; scratch >= 64*rows*cols floats
+int pn_launch_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols, int src_ld, float* dst,
+                          int ldd, int accumulate, float* scratch, hipStream_t s);
 int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s);
 
 struct PnSegTn {

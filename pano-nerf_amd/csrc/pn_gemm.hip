@@ -15,12 +15,87 @@
 // form each lane reads FOUR consecutive k of its row with one ds_read_b128 (lanes 0-31: k = 8j..8j+3,
 // lanes 32-63: k = 8j+4..8j+7) and feeds them to four consecutive MFMAs.
 #include "pn_common.h"
+#include <vector>
+
+// ---------------------------------------------------------------------------- launch timing
+// Optional (off by default): bracket every GEMM launch with HIP events on the launch stream so that
+// bench.py can report the dominant kernel's average duration and algorithmic FLOP rate live.
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+    double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_free_events;
+static double g_prof_ms[2] = {0, 0}, g_prof_flops[2] = {0, 0};
+static int64_t g_prof_n[2] = {0, 0};
+
+static hipEvent_t prof_event() {
+    if (!g_free_events.empty()) {
+        hipEvent_t e = g_free_events.back();
+        g_free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct ProfScope {
+    ProfRec r;
+    hipStream_t s;
+    bool live;
+    ProfScope(int cls, double flops, hipStream_t s_) : s(s_), live(false) {
+        if (!g_prof_on || g_prof.size() > (1u << 20)) return;
+        r.cls = cls;
+        r.flops = flops;
+        r.e0 = prof_event();
+        r.e1 = prof_event();
+        if (!r.e0 || !r.e1) return;
+        live = hipEventRecord(r.e0, s) == hipSuccess;
+    }
+    ~ProfScope() {
+        if (live && hipEventRecord(r.e1, s) == hipSuccess) g_prof.push_back(r);
+    }
+};
+static void prof_drain() {
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            g_prof_ms[r.cls] += ms;
+            g_prof_flops[r.cls] += r.flops;
+            g_prof_n[r.cls] += 1;
+        }
+        g_free_events.push_back(r.e0);
+        g_free_events.push_back(r.e1);
+    }
+    g_prof.clear();
+}
+extern "C" int pn_prof_enable(int on) {
+    prof_drain();
+    g_prof_on = on != 0;
+    for (int i = 0; i < 2; ++i) {
+        g_prof_ms[i] = 0;
+        g_prof_flops[i] = 0;
+        g_prof_n[i] = 0;
+    }
+    return PN_OK;
+}
+extern "C" int pn_prof_read(int cls, double* total_ms, int64_t* launches, double* flops) {
+    if (cls < 0 || cls > 1) return PN_ERR_BAD_SHAPE;
+    prof_drain();
+    if (total_ms) *total_ms = g_prof_ms[cls];
+    if (launches) *launches = g_prof_n[cls];
+    if (flops) *flops = g_prof_flops[cls];
+    return PN_OK;
+}
 
 #define BM 128
 #define BN 128
 #define BK 32
 #define LDT (BK + 4)   // NT tiles: [128][36] floats; +4 keeps 16-B alignment and is conflict-free for b128
 #define LDX (BM + 4)   // TN tiles: [32][132] floats
+#define EPL 68         // epilogue transposition rows: 64 + 4 floats
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // blocks b and b+8 share an XCD: give each XCD a contiguous range of tiles (bijective form).
@@ -95,7 +170,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nw
 
     for (int c = 0; c < nchunks; ++c) {
         const int cn = c + 1;
-        if (cn < nchunks) {
+        if (cn < nchunks && !(g.flags & 0x200)) {
             int seg = cn >= nc0 ? 1 : 0;
             nt_load(g, seg, (seg ? cn - nc0 : cn) * BK, m0, n0, tid, regs);
         }
@@ -120,30 +195,86 @@ __global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nw
         }
     }
 
-    // epilogue: acc[tm][tn][r] -> C[row][col], row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    // ---- epilogue.  The accumulators hold one column per lane (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), so a
+    // direct store is 64 dword stores per lane, each touching two 128-B row segments.  Instead every wave
+    // transposes its 32x64 half-tile through the (now free) staging LDS and streams full 256-B row segments
+    // as float4; bias / per-ray bias / addend / ReLU / gate / mask bits / column sums are applied there.
     const int flags = g.flags;
+    float* Ls = smem + wid * (32 * EPL);
+    const int col4 = (lane & 15) * 4;  // column of this lane's float4 inside the wave's 64 columns
+    const int gcol = n0 + wn * 64 + col4;
+    const bool col_ok = gcol < g.N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if ((flags & PN_EPI_BIAS) && col_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + gcol);
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();  // every wave is done reading As / Bs
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
-            if (col >= g.N) continue;
-            const float bias = (flags & PN_EPI_BIAS) ? g.bias[col] : 0.f;
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
-                float v = acc[tm][tn][r] + bias;
+            for (int r = 0; r < 16; ++r)
+                Ls[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPL + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lrow = (lane >> 4) + 4 * i;
+            const int64_t row = m0 + wm * 64 + tm * 32 + lrow;
+            const bool ok = col_ok && row < g.M;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ls + lrow * EPL + col4);
+            v += bias4;
+            if (ok) {
                 if (flags & PN_EPI_ROWBIAS) {
                     int64_t ray = row / g.rows_per_ray;
                     if (g.rb_mod > 0) ray %= g.rb_mod;
-                    v += g.rowbias[ray * g.ldrb + col];
+                    v += *reinterpret_cast<const f32x4*>(g.rowbias + ray * g.ldrb + gcol);
                 }
-                if (flags & PN_EPI_ADDC) v += g.addc[row * g.ldadd + col];
-                if (flags & PN_EPI_RELU) v = fmaxf(v, 0.f);
-                if (flags & PN_EPI_GATE) v = (g.gate[row * g.ldg + col] > 0.f) ? v : 0.f;
-                g.C[row * g.ldc + col] = v;
+                if (flags & PN_EPI_ADDC) v += *reinterpret_cast<const f32x4*>(g.addc + row * g.ldadd + gcol);
             }
+            if (flags & PN_EPI_RELU) {
+                v[0] = fmaxf(v[0], 0.f);
+                v[1] = fmaxf(v[1], 0.f);
+                v[2] = fmaxf(v[2], 0.f);
+                v[3] = fmaxf(v[3], 0.f);
+            }
+            if ((flags & PN_EPI_GATE) && ok) {
+                f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + row * g.ldg + gcol);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = gt[c] > 0.f ? v[c] : 0.f;
+            }
+            if ((flags & PN_EPI_GATEBITS) && ok) {
+                uint32_t w = g.gate_bits[row * PN_MASK_WORDS + (gcol >> 5)];
+                const int bi = (gcol >> 2) & 7;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = ((w >> (c * 8 + bi)) & 1u) ? v[c] : 0.f;
+            }
+            if (flags & PN_EPI_MASKOUT) {  // all 64 lanes take part in the ballots
+                uint32_t word = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned long long b = __ballot(v[c] > 0.f);
+                    word |= (uint32_t)((b >> ((lane >> 3) * 8)) & 0xffull) << (c * 8);
+                }
+                if (ok && (lane & 7) == 0) g.mask_out[row * PN_MASK_WORDS + (gcol >> 5)] = word;
+            }
+            if (ok) {
+                if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + gcol) = v;
+                csum += v;
+            }
+        }
+        __syncthreads();
+    }
+    if (flags & PN_EPI_COLSUM) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = csum[c];
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            csum[c] = x;
+        }
+        if (lane < 16 && col_ok) {
+            const int64_t prow = (m0 / 64) + wm;
+            *reinterpret_cast<f32x4*>(g.colsum + prow * g.N + gcol) = csum;
         }
     }
 }
@@ -161,10 +292,18 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     if ((g.flags & PN_EPI_GATE) && !g.gate) return PN_ERR_NULL;
     if ((g.flags & PN_EPI_ROWBIAS) && (!g.rowbias || g.rows_per_ray <= 0)) return PN_ERR_NULL;
     if ((g.flags & PN_EPI_ADDC) && !g.addc) return PN_ERR_NULL;
+    if ((g.flags & PN_EPI_GATEBITS) && !g.gate_bits) return PN_ERR_NULL;
+    if ((g.flags & PN_EPI_MASKOUT) && !g.mask_out) return PN_ERR_NULL;
+    if ((g.flags & PN_EPI_COLSUM) && !g.colsum) return PN_ERR_NULL;
+    if ((g.N & 3) || (g.ldc & 3)) return PN_ERR_BAD_SHAPE;
+    if ((g.flags & PN_EPI_GATE) && (g.ldg & 3)) return PN_ERR_BAD_SHAPE;
     int64_t tiles_m = (g.M + BM - 1) / BM;
     int tiles_n = (g.N + BN - 1) / BN;
     int64_t nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffff) return PN_ERR_BAD_SHAPE;
+    double ksum = 0;
+    for (int i = 0; i < g.nseg; ++i) ksum += g.seg[i].K;
+    ProfScope prof(0, 2.0 * (double)g.M * g.N * ksum, s);
     hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, g, tiles_n, (int)nwg);
     PN_CHECK_LAUNCH();
     return PN_OK;
@@ -276,15 +415,52 @@ __global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2) {
         }
 }
 
-__global__ void k_reduce_slabs(const float* slab, int nsplit, int N1, int N2, float* C, int ldc, int accumulate) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t n = (int64_t)N1 * N2;
-    if (idx >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * n + idx];
-    int i = (int)(idx / N2), j = (int)(idx % N2);
-    float* dst = C + (int64_t)i * ldc + j;
-    *dst = accumulate ? (*dst + s) : s;
+// Deterministic sum over a leading "partials" dimension: out[e] = sum_b src[b*stride + e'] for the
+// elements e of a [rows, cols] block.  One block = 64 elements x 4 partial lanes; grid.y splits the partials.
+__global__ __launch_bounds__(256) void k_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols,
+                                                      int src_ld, float* dst, int64_t dst_stride, int ldd,
+                                                      int accumulate) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    const int64_t per = (nb + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = (int64_t)blockIdx.y * per;
+    int64_t b1 = b0 + per;
+    if (b1 > nb) b1 = nb;
+    float acc = 0.f;
+    int r = 0, c = 0;
+    if (e < rows * cols) {
+        r = e / cols;
+        c = e % cols;
+        const float* p = src + (int64_t)r * src_ld + c;
+        for (int64_t b = b0 + ty; b < b1; b += 4) acc += p[b * stride];
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && e < rows * cols) {
+        float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        float* d = dst + blockIdx.y * dst_stride + (int64_t)r * ldd + c;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+
+int pn_launch_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols, int src_ld, float* dst,
+                          int ldd, int accumulate, float* scratch, hipStream_t s) {
+    const int n = rows * cols;
+    const unsigned gx = (unsigned)((n + 63) / 64);
+    if (nb > 256 && scratch) {  // two stages: 64 partial sums, then the final (accumulating) one
+        hipLaunchKernelGGL(k_reduce_rows, dim3(gx, 64), dim3(256), 0, s, src, nb, stride, rows, cols, src_ld, scratch,
+                           (int64_t)n, cols, 0);
+        PN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_reduce_rows, dim3(gx, 1), dim3(256), 0, s, scratch, (int64_t)64, (int64_t)n, rows, cols,
+                           cols, dst, (int64_t)0, ldd, accumulate);
+        PN_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(k_reduce_rows, dim3(gx, 1), dim3(256), 0, s, src, nb, stride, rows, cols, src_ld, dst,
+                           (int64_t)0, ldd, accumulate);
+        PN_CHECK_LAUNCH();
+    }
+    return PN_OK;
 }
 
 static int tn_splits(int64_t Mtotal, int N1, int N2) {
@@ -324,11 +500,10 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
     g.rows_per_split = per * BK;
     g.slab = work;
     int tiles1 = (N1 + BM - 1) / BM, tiles2 = (N2 + BN - 1) / BN;
-    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles1 * tiles2, nsplit), dim3(256), 0, s, g, tiles2);
+    {
+        ProfScope prof(1, 2.0 * (double)Mtotal * N1 * N2, s);
+        hipLaunchKernelGGL(k_gemm_tn, dim3(tiles1 * tiles2, nsplit), dim3(256), 0, s, g, tiles2);
+    }
     PN_CHECK_LAUNCH();
-    int64_t n = (int64_t)N1 * N2;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, work, nsplit, N1, N2, C, ldc,
-                       accumulate);
-    PN_CHECK_LAUNCH();
-    return PN_OK;
+    return pn_launch_reduce_rows(work, nsplit, (int64_t)N1 * N2, N1, N2, N2, C, ldc, accumulate, nullptr, s);
 }

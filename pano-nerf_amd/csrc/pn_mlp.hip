@@ -17,6 +17,11 @@
 #include <math.h>
 
 #define ST(s) ((hipStream_t)(s))
+#define RUN(x)                  \
+    do {                        \
+        int rc_ = (x);          \
+        if (rc_ != PN_OK) return rc_; \
+    } while (0)
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
 // -------------------------------------------------------------------------------- layouts
@@ -186,17 +191,6 @@ __global__ __launch_bounds__(256) void k_head_bwd_weight(int64_t M, int rows_per
     for (int i = threadIdx.x; i < NC * K + NC; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-// dst[j] (+)= sum_blk partial[blk][off + j], j < n     (dst strided by ldd per row of `cols`)
-__global__ void k_reduce_partial(const float* partial, int nblk_, int stride, int off, int rows, int cols, int src_ld,
-                                 float* dst, int ldd) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    int r = idx / cols, c = idx % cols;
-    float s = 0.f;
-    for (int b = 0; b < nblk_; ++b) s += partial[(int64_t)b * stride + off + r * src_ld + c];
-    dst[(int64_t)r * ldd + c] += s;
-}
-
 // column sums: partial[blk][col] = sum_{rows of blk} X[row, col]
 __global__ __launch_bounds__(256) void k_colsum(int64_t M, int rows_per_block, const float* X, int ldx, int N,
                                                  float* partial) {
@@ -282,11 +276,6 @@ static void seg2(PnGemmNt& g, const float* A, int lda, const float* B, int ldb, 
     g.seg[1] = PnSeg{A, B, lda, ldb, K};
     g.nseg = 2;
 }
-#define RUN(x)                  \
-    do {                        \
-        int rc_ = (x);          \
-        if (rc_ != PN_OK) return rc_; \
-    } while (0)
 
 template <int VEC, int NC>
 static int head_fwd(int64_t M, const float* x, int ldx, const float* W, const float* b, float* out, int ldo,
@@ -312,13 +301,9 @@ static int head_bwd_weight(int64_t M, const float* d, int ldd, const float* coef
     hipLaunchKernelGGL((k_head_bwd_weight<VEC, NC>), dim3(nb), dim3(256), 0, s, M, HEAD_ROWS, d, ldd, coef, x, ldx,
                        partial);
     PN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_reduce_partial, dim3(nblk(NC * K, 256)), dim3(256), 0, s, partial, nb, NC * K + NC, 0, NC, K, K,
-                       dW, K);
-    PN_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(k_reduce_partial, dim3(1), dim3(256), 0, s, partial, nb, NC * K + NC, NC * K, 1, NC, NC, db, NC);
-        PN_CHECK_LAUNCH();
-    }
+    float* scratch = partial + (int64_t)nb * (NC * K + NC);
+    RUN(pn_launch_reduce_rows(partial, nb, NC * K + NC, NC, K, K, dW, K, 1, scratch, s));
+    if (db) RUN(pn_launch_reduce_rows(partial + NC * K, nb, NC * K + NC, 1, NC, NC, db, NC, 1, scratch, s));
     return PN_OK;
 }
 #define COLSUM_ROWS 256
@@ -326,9 +311,7 @@ static int colsum_into(int64_t M, const float* X, int ldx, int N, float* dst, fl
     int nb = (int)nblk(M, COLSUM_ROWS);
     hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, M, COLSUM_ROWS, X, ldx, N, partial);
     PN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_reduce_partial, dim3(1), dim3(256), 0, s, partial, nb, N, 0, 1, N, N, dst, N);
-    PN_CHECK_LAUNCH();
-    return PN_OK;
+    return pn_launch_reduce_rows(partial, nb, N, 1, N, N, dst, N, 1, partial + (int64_t)nb * N, s);
 }
 static int wgrad(int64_t M, const float* X, int ldx, int N1, const float* Y, int ldy, int N2, float* dW, int ldw,
                  float* work, hipStream_t s) {
@@ -384,11 +367,11 @@ int pn_pack_weights(const float* params, int nc, float* wpack, void* stream) {
 
 int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, const float* params, const float* wpack,
                    const float* mean, const float* cov, const float* viewdirs, float* enc, float* viewenc,
-                   float* viewbias, float* acts, float* raw_rgb, float* raw_density, void* stream) {
+                   float* viewbias, float* acts, uint32_t* masks, float* raw_rgb, float* raw_density, void* stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (!params || !wpack || !mean || !cov || !viewdirs || !enc || !viewenc || !viewbias || !acts || !raw_rgb ||
-        !raw_density)
+    if (!params || !wpack || !mean || !cov || !viewdirs || !enc || !viewenc || !viewbias || !acts || !masks ||
+        !raw_rgb || !raw_density)
         return PN_ERR_NULL;
     hipStream_t s = ST(stream);
     PnLayout L = pn_layout(nc);
@@ -415,7 +398,8 @@ int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, const
             g = nt(M, PN_WIDTH, act(l - 1), PN_WIDTH, params + L.w[l], PN_WIDTH, PN_WIDTH, act(l), PN_WIDTH);
         }
         g.bias = params + L.b[l];
-        g.flags = PN_EPI_BIAS | PN_EPI_RELU;
+        g.mask_out = masks + (int64_t)l * Mp * PN_MASK_WORDS;
+        g.flags = PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_MASKOUT;
         RUN(pn_launch_gemm_nt(g, s));
     }
     // density head
@@ -435,7 +419,8 @@ int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, const
         g.ldrb = PN_WIDTH_COND;
         g.rows_per_ray = rows_per_ray;
         g.rb_mod = view_rows;
-        g.flags = PN_EPI_ROWBIAS | PN_EPI_RELU;
+        g.mask_out = masks + (int64_t)8 * Mp * PN_MASK_WORDS;
+        g.flags = PN_EPI_ROWBIAS | PN_EPI_RELU | PN_EPI_MASKOUT;
         RUN(pn_launch_gemm_nt(g, s));
     }
     RUN((head_fwd<2, 3>(M, act(9), PN_WIDTH, params + L.wc, params + L.bc, raw_rgb, 3, s)));
@@ -443,11 +428,11 @@ int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, const
 }
 
 int pn_density_grad(int64_t M, int nc, float density_bias, const float* params, const float* wpack, const float* mean,
-                    const float* cov, const float* acts, const float* raw_density, float* rsweep, float* scratch,
-                    float* grad_mean, void* stream) {
+                    const float* cov, const float* acts, const uint32_t* masks, const float* raw_density, float* rsweep,
+                    float* scratch, float* grad_mean, void* stream) {
     if (M <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (!params || !wpack || !mean || !cov || !acts || !raw_density || !rsweep || !scratch || !grad_mean)
+    if (!params || !wpack || !mean || !cov || !acts || !masks || !raw_density || !rsweep || !scratch || !grad_mean)
         return PN_ERR_NULL;
     hipStream_t s = ST(stream);
     PnLayout L = pn_layout(nc);
@@ -460,9 +445,8 @@ int pn_density_grad(int64_t M, int nc, float density_bias, const float* params, 
     PN_CHECK_LAUNCH();
     for (int l = 7; l >= 1; --l) {  // r_{l-1} = [h_{l-1} > 0] * (r_l * W_l[:, :256])
         PnGemmNt g = nt(M, PN_WIDTH, rs(l), PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, rs(l - 1), PN_WIDTH);
-        g.gate = act(l - 1);
-        g.ldg = PN_WIDTH;
-        g.flags = PN_EPI_GATE;
+        g.gate_bits = masks + (int64_t)(l - 1) * Mp * PN_MASK_WORDS;
+        g.flags = PN_EPI_GATEBITS;
         RUN(pn_launch_gemm_nt(g, s));
     }
     {  // d sigma / d enc = r_0 * W_0 + r_5 * W_5[:, 256:]
@@ -485,22 +469,23 @@ int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows) {
     n += Mp * 32;                 // expanded viewenc
     n += Mp * 8 + Mp * 2;         // dden copy, sdot, coef
     n += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);  // slabs
+    n += (Mp / 64) * PN_WIDTH + 64 * PN_WIDTH;           // epilogue column sums + reduce scratch
     int64_t nb = (M + HEAD_ROWS - 1) / HEAD_ROWS;
-    int64_t hp = nb * (5 * PN_WIDTH + 5);
-    int64_t cp = ((M + COLSUM_ROWS - 1) / COLSUM_ROWS) * PN_WIDTH;
-    n += (hp > cp ? hp : cp) + 64;
+    int64_t hp = nb * (5 * PN_WIDTH + 5) + 64 * (5 * PN_WIDTH + 5);
+    int64_t cp = ((M + COLSUM_ROWS - 1) / COLSUM_ROWS) * PN_WIDTH + 64 * PN_WIDTH;
+    n += (hp > cp ? hp : cp) + 128 * 32 + 64;
     (void)view_rows;
     return n;
 }
 
 int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, float density_bias, const float* params,
                     const float* wpack, const float* mean, const float* cov, const float* enc, const float* viewenc,
-                    const float* acts, const float* raw_density, const float* d_raw_rgb, const float* d_raw_density,
-                    const float* rsweep, const float* v_gradmean, float* d_mean, float* grads, float* work,
-                    void* stream) {
+                    const float* acts, const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
+                    const float* d_raw_density, const float* rsweep, const float* v_gradmean, float* d_mean,
+                    float* grads, float* work, void* stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (!params || !wpack || !mean || !cov || !enc || !viewenc || !acts || !raw_density || !d_raw_rgb ||
+    if (!params || !wpack || !mean || !cov || !enc || !viewenc || !acts || !masks || !raw_density || !d_raw_rgb ||
         !d_raw_density || !grads || !work)
         return PN_ERR_NULL;
     if (v_gradmean && !rsweep) return PN_ERR_NULL;
@@ -525,7 +510,15 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     float* sdot = w; w += Mp;
     float* coef = w; w += Mp;
     float* slab = w; w += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);
+    float* csum = w; w += (Mp / 64) * PN_WIDTH;   // per-wave column sums written by the GEMM epilogues
+    float* csum_scratch = w; w += 64 * PN_WIDTH;
     float* partial = w;
+    auto mask = [&](int i) { return masks + (int64_t)i * Mp * PN_MASK_WORDS; };
+    const int64_t csum_rows = 2 * ((M + 127) / 128);
+    auto bias_grad = [&](int64_t off) {
+        return pn_launch_reduce_rows(csum, csum_rows, PN_WIDTH, 1, PN_WIDTH, PN_WIDTH, grads + off, PN_WIDTH, 1,
+                                     csum_scratch, s);
+    };
     const int ld5 = PN_WIDTH + PN_ENC_DIM;
     const int ldv = PN_WIDTH + PN_VIEW_DIM;
 
@@ -552,9 +545,8 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
             } else {
                 g = nt(M, PN_WIDTH, prev, PN_WIDTH, params + L.w[l], PN_WIDTH, PN_WIDTH, cur, PN_WIDTH);
             }
-            g.gate = act(l);
-            g.ldg = PN_WIDTH;
-            g.flags = PN_EPI_GATE;
+            g.gate_bits = mask(l);
+            g.flags = PN_EPI_GATEBITS;
             RUN(pn_launch_gemm_nt(g, s));
             prev = cur;
             prev_ld = PN_WIDTH;
@@ -581,17 +573,17 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         // [128][32] product; only the first 27 columns exist in the parameter: land it in scratch, then add
         float* tmp = partial;  // 128*32 floats
         RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, tmp, 32, 0, slab, s));
-        hipLaunchKernelGGL(k_reduce_partial, dim3(nblk(PN_WIDTH_COND * PN_VIEW_DIM, 256)), dim3(256), 0, s, tmp, 1, 0, 0,
-                           PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv);
-        PN_CHECK_LAUNCH();
+        RUN(pn_launch_reduce_rows(tmp, 1, 0, PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv, 1, nullptr, s));
     }
     RUN(colsum_into(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv, partial, s));
     {  // d bottleneck = dvh * Wv[:, :256]
         PnGemmNt g = nt(M, PN_WIDTH, dvh, PN_WIDTH_COND, wpack + P.wvm_t, PN_WIDTH_COND, PN_WIDTH_COND, dbott, PN_WIDTH);
+        g.colsum = csum;
+        g.flags = PN_EPI_COLSUM;
         RUN(pn_launch_gemm_nt(g, s));
     }
+    RUN(bias_grad(L.be));
     RUN(wgrad(M, dbott, PN_WIDTH, PN_WIDTH, act(7), PN_WIDTH, PN_WIDTH, grads + L.we, PN_WIDTH, slab, s));
-    RUN(colsum_into(M, dbott, PN_WIDTH, PN_WIDTH, grads + L.be, partial, s));
     // ---------------- density head ----------------------------------------------------------
     float* d7 = delta[1];
     if (nc == 5) {
@@ -605,11 +597,12 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         PnGemmNt g = nt(M, PN_WIDTH, dbott, PN_WIDTH, wpack + P.we_t, PN_WIDTH, PN_WIDTH, d7, PN_WIDTH);
         g.addc = delta[0];
         g.ldadd = PN_WIDTH;
-        g.gate = act(7);
-        g.ldg = PN_WIDTH;
-        g.flags = PN_EPI_ADDC | PN_EPI_GATE;
+        g.gate_bits = mask(7);
+        g.colsum = csum;
+        g.flags = PN_EPI_ADDC | PN_EPI_GATEBITS | PN_EPI_COLSUM;
         RUN(pn_launch_gemm_nt(g, s));
     }
+    RUN(bias_grad(L.b[7]));
     // ---------------- trunk ---------------------------------------------------------------------
     float* cur = d7;
     float* d5 = nullptr;
@@ -620,7 +613,6 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         int ldw = (l == 0) ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH);
         RUN(wgrad(M, cur, PN_WIDTH, PN_WIDTH, xin, ldx, kin, grads + L.w[l], ldw, slab, s));
         if (l == 5) RUN(wgrad(M, cur, PN_WIDTH, PN_WIDTH, enc, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, s));
-        RUN(colsum_into(M, cur, PN_WIDTH, PN_WIDTH, grads + L.b[l], partial, s));
         if (l == 5 && d_mean) {
             // keep delta_5 alive for the d_enc GEMM: park it in the tangent buffer (free by now)
             if (hipMemcpyAsync(tang[0], cur, sizeof(float) * M * PN_WIDTH, hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -630,10 +622,11 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         if (l > 0) {
             float* nxt = (cur == delta[0]) ? delta[1] : delta[0];
             PnGemmNt g = nt(M, PN_WIDTH, cur, PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, nxt, PN_WIDTH);
-            g.gate = act(l - 1);
-            g.ldg = PN_WIDTH;
-            g.flags = PN_EPI_GATE;
+            g.gate_bits = mask(l - 1);
+            g.colsum = csum;
+            g.flags = PN_EPI_GATEBITS | PN_EPI_COLSUM;
             RUN(pn_launch_gemm_nt(g, s));
+            RUN(bias_grad(L.b[l - 1]));
             cur = nxt;
         }
     }
@@ -652,7 +645,7 @@ int pn_gemm_nt(int64_t M, int N, int K, const float* A, int lda, const float* Bt
     g.bias = bias;
     g.gate = gate;
     g.ldg = ldg;
-    g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE);
+    g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE | 0x300);  // 0x100/0x200: ablation (tools/bench_gemm.py)
     return pn_launch_gemm_nt(g, ST(stream));
 }
 

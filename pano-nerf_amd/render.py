@@ -35,6 +35,7 @@ class _Eval:
         self.enc = e(Mp, 96)
         self.viewenc, self.viewbias = e(self.view_rows, 27), e(self.view_rows, 128)
         self.acts = e(10, Mp, 256)
+        self.masks = torch.empty(9, Mp, 8, dtype=torch.int32, device=dev)  # ReLU gates as bit masks
         self.raw_rgb, self.raw_den = e(M, 3), e(M, nc)
         self.t = None
         self.rsweep = None
@@ -51,7 +52,8 @@ class _Cfg:
 def _mlp_forward(ev, params, wpack, st):
     _lib.call("pn_mlp_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, params.data_ptr(), wpack.data_ptr(),
               ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
-              ev.viewbias.data_ptr(), ev.acts.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), st)
+              ev.viewbias.data_ptr(), ev.acts.data_ptr(), ev.masks.data_ptr(), ev.raw_rgb.data_ptr(),
+              ev.raw_den.data_ptr(), st)
 
 
 def _composite_forward(ev, R, N, cfg, white, dirs, dir_mod, st):
@@ -77,7 +79,7 @@ def _mlp_backward(ev, cfg, params, wpack, d_raw_rgb, d_raw_den, v, d_mean, flat_
     work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
     _lib.call("pn_mlp_backward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, cfg.density_bias, params.data_ptr(),
               wpack.data_ptr(), ev.mean.data_ptr(), ev.cov.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
-              ev.acts.data_ptr(), ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(),
+              ev.acts.data_ptr(), ev.masks.data_ptr(), ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(),
               _lib.ptr(ev.rsweep), _lib.ptr(v), _lib.ptr(d_mean), flat_grad.data_ptr(), work.data_ptr(), st)
 
 
@@ -121,8 +123,8 @@ class _RenderFn(torch.autograd.Function):
                 e1.gmean = e(M, 3)
                 scratch = e(e1.Mp, 96)
                 _lib.call("pn_density_grad", M, nc, cfg.density_bias, params.data_ptr(), wpack.data_ptr(),
-                          e1.mean.data_ptr(), e1.cov.data_ptr(), e1.acts.data_ptr(), e1.raw_den.data_ptr(),
-                          e1.rsweep.data_ptr(), scratch.data_ptr(), e1.gmean.data_ptr(), st)
+                          e1.mean.data_ptr(), e1.cov.data_ptr(), e1.acts.data_ptr(), e1.masks.data_ptr(),
+                          e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), scratch.data_ptr(), e1.gmean.data_ptr(), st)
                 normal = e(B, 3)
                 ort_ray = e(B) if cfg.use_ort else None
                 albedo = e(B, 3) if (cfg.surf and nc == 5) else None

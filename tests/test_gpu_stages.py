@@ -172,11 +172,11 @@ def _mlp_eval(lib, p_flat, wpack, nc, mean, cov, viewdirs, rows_per_ray):
     Mp = int(lib.load().pn_pad_rows(M))
     R = viewdirs.shape[0]
     buf = dict(enc=E(Mp, 96), viewenc=E(R, 27), viewbias=E(R, 128), acts=E(10, Mp, 256), raw_rgb=E(M, 3),
-               raw_den=E(M, nc))
+               raw_den=E(M, nc), masks=torch.empty(9, Mp, 8, dtype=torch.int32, device=dev()))
     lib.call("pn_mlp_forward", M, rows_per_ray, R, nc, p_flat.data_ptr(), wpack.data_ptr(), mean.data_ptr(),
              cov.data_ptr(), viewdirs.data_ptr(), buf["enc"].data_ptr(), buf["viewenc"].data_ptr(),
-             buf["viewbias"].data_ptr(), buf["acts"].data_ptr(), buf["raw_rgb"].data_ptr(), buf["raw_den"].data_ptr(),
-             st())
+             buf["viewbias"].data_ptr(), buf["acts"].data_ptr(), buf["masks"].data_ptr(), buf["raw_rgb"].data_ptr(),
+             buf["raw_den"].data_ptr(), st())
     return buf
 
 
@@ -207,7 +207,8 @@ def test_mlp_forward_and_density_grad(lib, golden, case):
     Mp = int(lib.load().pn_pad_rows(M))
     rs, scratch, gm = E(8, Mp, 256), E(Mp, 96), E(M, 3)
     lib.call("pn_density_grad", M, 5, -1.0, flat.data_ptr(), wpack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
-             buf["acts"].data_ptr(), buf["raw_den"].data_ptr(), rs.data_ptr(), scratch.data_ptr(), gm.data_ptr(), st())
+             buf["acts"].data_ptr(), buf["masks"].data_ptr(), buf["raw_den"].data_ptr(), rs.data_ptr(),
+             scratch.data_ptr(), gm.data_ptr(), st())
     got = C(gm).view(B, N, 3)
     p64 = {k: v.double() for k, v in params.items()}
     torch.set_default_dtype(torch.float64)

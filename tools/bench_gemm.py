@@ -1,0 +1,29 @@
+"""Micro-benchmark of the two GEMM kernels at the bench shapes (GPU box)."""
+import sys, os, ctypes
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import torch
+from pano_nerf_amd import _lib as lib
+
+dev = torch.device("cuda:0")
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+st = torch.cuda.current_stream().cuda_stream
+A = torch.randn(M, 256, device=dev); W = torch.randn(256, 256, device=dev) * 0.06
+C = torch.empty(M, 256, device=dev); gate = torch.randn(M, 256, device=dev); bias = torch.randn(256, device=dev)
+for name, N, K, flags in (("nt 256x256 bias+relu", 256, 256, 3), ("nt 256x256 gate", 256, 256, 4), ("nt 256x256 plain", 256, 256, 0),
+                          ("nt plain nostore", 256, 256, 0x100), ("nt plain noload", 256, 256, 0x200), ("nt noload nostore", 256, 256, 0x300),
+                          ("nt 256x96(K) bias+relu", 256, 96, 3), ("nt N=96 K=256", 96, 256, 0), ("nt N=128 K=256", 128, 256, 2)):
+    ms = timeit(lambda: lib.call("pn_gemm_nt", M, N, K, A.data_ptr(), 256, W.data_ptr(), 256, C.data_ptr(), 256, bias.data_ptr(), gate.data_ptr(), 256, flags, st))
+    print(f"{name:28s} {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF")
+X = torch.randn(M, 256, device=dev); Y = torch.randn(M, 256, device=dev); Cw = torch.zeros(256, 256, device=dev)
+work = torch.empty(int(lib.load().pn_gemm_tn_work_floats(M, 256, 256)), device=dev)
+for name, N1, N2 in (("tn 256x256", 256, 256), ("tn 256x96", 256, 96), ("tn 128x256", 128, 256)):
+    ms = timeit(lambda: lib.call("pn_gemm_tn", M, N1, N2, X.data_ptr(), 256, Y.data_ptr(), 256, Cw.data_ptr(), 256, 1, work.data_ptr(), st))
+    print(f"{name:28s} {ms*1e3:8.1f} us  {2*M*N1*N2/ms/1e9:7.1f} TF (incl. slab reduce)")

@@ -18,7 +18,7 @@ for case in ("B64_N32", "B16_N128"):
     Mp = int(lib.load().pn_pad_rows(M))
     rs, scratch, gm = T.E(8, Mp, 256), T.E(Mp, 96), T.E(M, 3)
     lib.call("pn_density_grad", M, 5, -1.0, flat.data_ptr(), wpack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
-             buf["acts"].data_ptr(), buf["raw_den"].data_ptr(), rs.data_ptr(), scratch.data_ptr(), gm.data_ptr(), T.st())
+             buf["acts"].data_ptr(), buf["masks"].data_ptr(), buf["raw_den"].data_ptr(), rs.data_ptr(), scratch.data_ptr(), gm.data_ptr(), T.st())
     got = T.C(gm).view(B, N, 3).double()
     def oracle(dt):
         torch.set_default_dtype(dt)
