@@ -66,9 +66,17 @@ def cpu_baseline(n_samples, rays_cpu, rgbs_cpu, env_cpu, b_cpu):
     t0 = time.perf_counter()
     step(*sub(b_cpu))
     dt = time.perf_counter() - t0
-    return {"value": b_cpu / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 train step (fwd+bwd+Adam, faithful vmap(jacrev) normals) on {b_cpu} rays x {n_samples}+"
-                      f"{n_samples} samples of the same synthetic batch, fp32, {dt:.1f} s"}
+    out = {"value": b_cpu / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"1 train step (fwd+bwd+Adam, faithful vmap(jacrev) normals) on {b_cpu} rays x {n_samples}+"
+                     f"{n_samples} samples of the same synthetic batch, fp32, {dt:.1f} s"}
+    cal = os.path.join(ROOT, "tests", "golden", "ref_cpu_timing.json")
+    if os.path.exists(cal):  # port-vs-imported-reference speed ratio measured in the build container (8 vCPU)
+        try:
+            runs = [r for r in json.load(open(cal))["runs"] if r["model"] == "pano"]
+            out["port_over_reference_speed"] = max(r["oracle_faithful_over_reference"] for r in runs)
+        except Exception:
+            pass
+    return out
 
 
 def main():

@@ -216,6 +216,8 @@ int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* 
  * While enabled every GEMM launch is bracketed by HIP events on its own stream.  pn_prof_read waits
  * for the recorded events and returns, for kernel class cls (0 = k_gemm_nt, 1 = k_gemm_tn), the summed
  * duration in ms, the launch count and the summed algorithmic FLOPs (2*M*N*K, unpadded). */
+/* diagnostic: `blocks` workgroups x 4 waves each issue 4*iters back-to-back fp32 MFMAs (no memory traffic) */
+int pn_mfma_probe(float* out, int blocks, int iters, void* stream);
 int pn_prof_enable(int on);
 int pn_prof_read(int cls, double* total_ms, int64_t* launches, double* flops);
 

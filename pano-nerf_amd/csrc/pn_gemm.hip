@@ -26,6 +26,7 @@ struct ProfRec {
     double flops;
 };
 static bool g_prof_on = false;
+static int g_dbg = 0;  // ablation switches (tools/bench_gemm.py): pn_prof_enable(on | dbg << 8)
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_free_events;
 static double g_prof_ms[2] = {0, 0}, g_prof_flops[2] = {0, 0};
@@ -73,7 +74,8 @@ static void prof_drain() {
 }
 extern "C" int pn_prof_enable(int on) {
     prof_drain();
-    g_prof_on = on != 0;
+    g_prof_on = (on & 1) != 0;
+    g_dbg = on >> 8;
     for (int i = 0; i < 2; ++i) {
         g_prof_ms[i] = 0;
         g_prof_flops[i] = 0;
@@ -109,21 +111,28 @@ struct NtRegs {
     f32x4 a[4], b[4];
 };
 
-__device__ __forceinline__ void nt_load(const PnGemmNt& g, int seg, int k0, int64_t m0, int n0, int tid, NtRegs& r) {
-    const PnSeg& s = g.seg[seg];
+// Branch-free staging loads: addresses are clamped into the operand (always legal to read) and the
+// out-of-range lanes are zeroed by a select, so no exec-mask branches and no scalar (kernarg) loads sit
+// inside the K loop (an s_waitcnt lgkmcnt(0) for an s_load would also drain the LDS reads).
+__device__ __forceinline__ void nt_load(const float* A, int lda, const float* B, int ldb, int K, int64_t M, int N,
+                                        int k0, int64_t m0, int n0, int tid, NtRegs& r) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int idx = tid + 256 * i;
         int row = idx >> 3, c4 = idx & 7;
         int k = k0 + c4 * 4;
+        const bool kin = k < K;
+        const int kc = kin ? k : K - 4;
         int64_t gr = m0 + row;
-        if (gr >= g.M) gr = g.M - 1;
-        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-        if (k < s.K) va = *reinterpret_cast<const f32x4*>(s.A + gr * s.lda + k);
+        gr = gr < M ? gr : M - 1;
         int gn = n0 + row;
-        if (k < s.K && gn < g.N) vb = *reinterpret_cast<const f32x4*>(s.B + (int64_t)gn * s.ldb + k);
-        r.a[i] = va;
-        r.b[i] = vb;
+        const bool nin = gn < N;
+        gn = nin ? gn : N - 1;
+        f32x4 va = *reinterpret_cast<const f32x4*>(A + gr * lda + kc);
+        f32x4 vb = *reinterpret_cast<const f32x4*>(B + (int64_t)gn * ldb + kc);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        r.a[i] = kin ? va : z;
+        r.b[i] = (kin && nin) ? vb : z;
     }
 }
 
@@ -137,15 +146,42 @@ __device__ __forceinline__ void nt_store(float* As, float* Bs, int tid, const Nt
     }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nwg) {
+__global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int ntiles) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDT];
     float* As = smem;
     float* Bs = smem + BM * LDT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int t = xcd_remap(blockIdx.x, nwg);
+
+    // chunk schedule over the (up to two) K segments
+    const int nc0 = (g.seg[0].K + BK - 1) / BK;
+    const int nc1 = (g.nseg > 1) ? (g.seg[1].K + BK - 1) / BK : 0;
+    const int nchunks = nc0 + nc1;
+    // segment descriptors as scalars (selected with s_cselect in the loop, never re-read from kernarg memory)
+    const float* const A0 = g.seg[0].A;
+    const float* const B0 = g.seg[0].B;
+    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb, K0 = g.seg[0].K;
+    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
+    const float* const B1 = g.nseg > 1 ? g.seg[1].B : B0;
+    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
+    const int K1 = g.nseg > 1 ? g.seg[1].K : K0;
+    const int64_t Mrows = g.M;
+    const int Ncols = g.N;
+    const int arow = (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int brow = (wn * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+
+    // One tile per workgroup.  Equal-length tiles keep the three resident workgroups of a CU in lockstep
+    // (load-only prologues and store-only epilogues coincide and idle the MFMA pipes), so the workgroups of
+    // the first residency round start a third of a tile apart; later workgroups inherit the offsets.
+    const int t = xcd_remap(blockIdx.x, ntiles);
     const int64_t m0 = (int64_t)(t / tiles_n) * BM;
     const int n0 = (t % tiles_n) * BN;
+    if (blockIdx.x < 768 && g.stagger > 0) {
+        const int slot = blockIdx.x / 256;  // which of the CU's resident workgroups (speed only)
+        for (int i = 0; i < slot * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    NtRegs regs;
+    nt_load(A0, lda0, B0, ldb0, K0, Mrows, Ncols, 0, m0, n0, tid, regs);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -155,24 +191,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nw
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // chunk schedule over the (up to two) K segments
-    const int nc0 = (g.seg[0].K + BK - 1) / BK;
-    const int nc1 = (g.nseg > 1) ? (g.seg[1].K + BK - 1) / BK : 0;
-    const int nchunks = nc0 + nc1;
-
-    NtRegs regs;
-    nt_load(g, 0, 0, m0, n0, tid, regs);
     nt_store(As, Bs, tid, regs);
     __syncthreads();
 
-    const int arow = (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
-    const int brow = (wn * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
-
     for (int c = 0; c < nchunks; ++c) {
         const int cn = c + 1;
-        if (cn < nchunks && !(g.flags & 0x200)) {
-            int seg = cn >= nc0 ? 1 : 0;
-            nt_load(g, seg, (seg ? cn - nc0 : cn) * BK, m0, n0, tid, regs);
+        if (!(g.flags & 0x200)) {
+            if (cn < nchunks) {
+                const bool s1 = cn >= nc0;
+                nt_load(s1 ? A1 : A0, s1 ? lda1 : lda0, s1 ? B1 : B0, s1 ? ldb1 : ldb0, s1 ? K1 : K0, Mrows, Ncols,
+                        (s1 ? cn - nc0 : cn) * BK, m0, n0, tid, regs);
+            }
         }
 #pragma unroll
         for (int j = 0; j < BK / 8; ++j) {
@@ -304,7 +333,34 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     double ksum = 0;
     for (int i = 0; i < g.nseg; ++i) ksum += g.seg[i].K;
     ProfScope prof(0, 2.0 * (double)g.M * g.N * ksum, s);
-    hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, g, tiles_n, (int)nwg);
+    PnGemmNt gg = g;
+    // stagger unit: ~1/3 of the time three co-resident tiles take, in s_sleep(127) quanta (8128 cycles each)
+    double tile_cycles = 3.0 * 64.0 * 64.0 * ((ksum + BK - 1) / BK);
+    gg.stagger = (nwg > 768 && !(g_dbg & 8)) ? (int)(tile_cycles / 3.0 / 8128.0 + 0.5) : 0;
+    if (g_dbg & 16) gg.stagger *= 2;
+    hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+// pure-MFMA loop (no memory): what the chip sustains on v_mfma_f32_32x32x2_f32 at its loaded clock
+__global__ __launch_bounds__(256) void k_mfma_probe(float* out, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = (float)threadIdx.x * 1e-3f, b = (float)blockIdx.x * 1e-4f + 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        a += 1e-6f;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 12345.678f) out[0] = s;
+}
+extern "C" int pn_mfma_probe(float* out, int blocks, int iters, void* stream) {
+    hipLaunchKernelGGL(k_mfma_probe, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
@@ -324,23 +380,24 @@ struct TnRegs {
     f32x4 x[4], y[4];
 };
 
-__device__ __forceinline__ void tn_load(const PnTnArgs& g, int64_t chunk, int i0, int j0, int tid, TnRegs& r) {
-    int sidx = chunk >= g.chunks0 ? 1 : 0;
-    const PnSegTn& s = g.seg[sidx];
-    int64_t r0 = (sidx ? chunk - g.chunks0 : chunk) * BK;
+__device__ __forceinline__ void tn_load(const float* X, int ldx, const float* Y, int ldy, int64_t Mseg, int N1, int N2,
+                                        int64_t r0, int i0, int j0, int tid, TnRegs& r) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int idx = tid + 256 * i;
         int row = idx >> 5, c4 = idx & 31;
         int64_t gr = r0 + row;
-        f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = {0.f, 0.f, 0.f, 0.f};
-        if (gr < s.M) {
-            int cx = i0 + c4 * 4, cy = j0 + c4 * 4;
-            if (cx < g.N1) vx = *reinterpret_cast<const f32x4*>(s.X + gr * s.ldx + cx);
-            if (cy < g.N2) vy = *reinterpret_cast<const f32x4*>(s.Y + gr * s.ldy + cy);
-        }
-        r.x[i] = vx;
-        r.y[i] = vy;
+        const bool rin = gr < Mseg;
+        gr = rin ? gr : Mseg - 1;
+        int cx = i0 + c4 * 4, cy = j0 + c4 * 4;
+        const bool xin = cx < N1, yin = cy < N2;
+        cx = xin ? cx : N1 - 4;
+        cy = yin ? cy : N2 - 4;
+        f32x4 vx = *reinterpret_cast<const f32x4*>(X + gr * ldx + cx);
+        f32x4 vy = *reinterpret_cast<const f32x4*>(Y + gr * ldy + cy);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        r.x[i] = (rin && xin) ? vx : z;
+        r.y[i] = (rin && yin) ? vy : z;
     }
 }
 
@@ -354,15 +411,19 @@ __device__ __forceinline__ void tn_store(float* Xs, float* Ys, int tid, const Tn
     }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2) {
+__global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2, int ntiles, int nsplit) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDX];
     float* Xs = smem;
     float* Ys = smem + BK * LDX;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int tile = blockIdx.x;
+    // blocks b and b+8 share an XCD (own L2): put the tiles of one row-split on one XCD, adjacent in
+    // dispatch order, so the X / Y panels they share are fetched from HBM once.
+    const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
+    const int tile = jj % ntiles;
+    const int64_t split = (int64_t)(jj / ntiles) * 8 + xcd;
+    if (split >= nsplit) return;
     const int i0 = (tile / tiles2) * BM, j0 = (tile % tiles2) * BN;
-    const int64_t split = blockIdx.y;
     const int64_t c_begin = split * (g.rows_per_split / BK);
     int64_t c_end = c_begin + g.rows_per_split / BK;
     if (c_end > g.chunks_total) c_end = g.chunks_total;
@@ -375,15 +436,30 @@ __global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const float* const X0 = g.seg[0].X;
+    const float* const Y0 = g.seg[0].Y;
+    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
+    const int64_t M0 = g.seg[0].M;
+    const float* const X1 = g.seg[1].X;
+    const float* const Y1 = g.seg[1].Y;
+    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
+    const int64_t M1 = g.seg[1].M;
+    const int64_t chunks0 = g.chunks0;
+    const int N1 = g.N1, N2 = g.N2;
+    auto load_chunk = [&](int64_t c, TnRegs& regs) {
+        const bool s1 = c >= chunks0;
+        tn_load(s1 ? X1 : X0, s1 ? ldx1 : ldx0, s1 ? Y1 : Y0, s1 ? ldy1 : ldy0, s1 ? M1 : M0, N1, N2,
+                (s1 ? c - chunks0 : c) * BK, i0, j0, tid, regs);
+    };
     if (c_begin < c_end) {
         TnRegs regs;
-        tn_load(g, c_begin, i0, j0, tid, regs);
+        load_chunk(c_begin, regs);
         tn_store(Xs, Ys, tid, regs);
         __syncthreads();
         const int xo = (lane >> 5) * LDX + wm * 64 + (lane & 31);
         const int yo = (lane >> 5) * LDX + wn * 64 + (lane & 31);
         for (int64_t c = c_begin; c < c_end; ++c) {
-            if (c + 1 < c_end) tn_load(g, c + 1, i0, j0, tid, regs);
+            if (c + 1 < c_end) load_chunk(c + 1, regs);
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 float a0 = Xs[xo + kk * 2 * LDX], a1 = Xs[xo + kk * 2 * LDX + 32];
@@ -502,7 +578,9 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
     int tiles1 = (N1 + BM - 1) / BM, tiles2 = (N2 + BN - 1) / BN;
     {
         ProfScope prof(1, 2.0 * (double)Mtotal * N1 * N2, s);
-        hipLaunchKernelGGL(k_gemm_tn, dim3(tiles1 * tiles2, nsplit), dim3(256), 0, s, g, tiles2);
+        const int ntiles = tiles1 * tiles2;
+        const int groups = (nsplit + 7) / 8;
+        hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
     }
     PN_CHECK_LAUNCH();
     return pn_launch_reduce_rows(work, nsplit, (int64_t)N1 * N2, N1, N2, N2, C, ldc, accumulate, nullptr, s);
