@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libpanonerf_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+FLAGS="$PN_EXTRA --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 for f in pn_gemm pn_render pn_mlp; do
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ pn_common.h -nt "$f.o" ] || [ ../../include/panonerf_hip.h -nt "$f.o" ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$f.hip" -o "$f.o"

@@ -146,7 +146,13 @@ __device__ __forceinline__ void nt_store(float* As, float* Bs, int tid, const Nt
     }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int ntiles) {
+#ifndef PN_NT_OCC
+#define PN_NT_OCC 3
+#endif
+#ifndef PN_NT_PREFETCH
+#define PN_NT_PREFETCH 1
+#endif
+__global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tiles_n, int ntiles) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDT];
     float* As = smem;
     float* Bs = smem + BM * LDT;
@@ -180,9 +186,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nt
         const int slot = blockIdx.x / 256;  // which of the CU's resident workgroups (speed only)
         for (int i = 0; i < slot * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    NtRegs regs;
-    nt_load(A0, lda0, B0, ldb0, K0, Mrows, Ncols, 0, m0, n0, tid, regs);
-
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -191,18 +194,14 @@ __global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nt
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    nt_store(As, Bs, tid, regs);
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-        const int cn = c + 1;
-        if (!(g.flags & 0x200)) {
-            if (cn < nchunks) {
-                const bool s1 = cn >= nc0;
-                nt_load(s1 ? A1 : A0, s1 ? lda1 : lda0, s1 ? B1 : B0, s1 ? ldb1 : ldb0, s1 ? K1 : K0, Mrows, Ncols,
-                        (s1 ? cn - nc0 : cn) * BK, m0, n0, tid, regs);
-            }
+    auto issue_load = [&](int cidx, NtRegs& r) {
+        if (cidx < nchunks && !(g.flags & 0x200)) {
+            const bool s1 = cidx >= nc0;
+            nt_load(s1 ? A1 : A0, s1 ? lda1 : lda0, s1 ? B1 : B0, s1 ? ldb1 : ldb0, s1 ? K1 : K0, Mrows, Ncols,
+                    (s1 ? cidx - nc0 : cidx) * BK, m0, n0, tid, r);
         }
+    };
+    auto compute = [&]() {
 #pragma unroll
         for (int j = 0; j < BK / 8; ++j) {
             f32x4 a0 = *reinterpret_cast<const f32x4*>(As + arow + j * 8);
@@ -217,12 +216,46 @@ __global__ __launch_bounds__(256) void k_gemm_nt(PnGemmNt g, int tiles_n, int nt
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
             }
         }
+    };
+#if PN_NT_PREFETCH == 2
+    // two K-chunks in flight in registers (rA: odd chunks, rB: even chunks), one staged in LDS
+    NtRegs rA, rB;
+    nt_load(A0, lda0, B0, ldb0, K0, Mrows, Ncols, 0, m0, n0, tid, rB);
+    nt_store(As, Bs, tid, rB);
+    issue_load(1, rA);
+    issue_load(2, rB);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        compute();  // chunk c
         __syncthreads();
-        if (cn < nchunks) {
+        if (c + 1 < nchunks) {
+            nt_store(As, Bs, tid, rA);  // chunk c+1
+            __syncthreads();
+            issue_load(c + 3, rA);
+            compute();
+            __syncthreads();
+            if (c + 2 < nchunks) {
+                nt_store(As, Bs, tid, rB);  // chunk c+2
+                __syncthreads();
+                issue_load(c + 4, rB);
+            }
+        }
+    }
+#else
+    NtRegs regs;
+    nt_load(A0, lda0, B0, ldb0, K0, Mrows, Ncols, 0, m0, n0, tid, regs);
+    nt_store(As, Bs, tid, regs);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        issue_load(c + 1, regs);
+        compute();
+        __syncthreads();
+        if (c + 1 < nchunks) {
             nt_store(As, Bs, tid, regs);
             __syncthreads();
         }
     }
+#endif
 
     // ---- epilogue.  The accumulators hold one column per lane (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), so a
     // direct store is 64 dword stores per lane, each touching two 128-B row segments.  Instead every wave
@@ -491,6 +524,129 @@ __global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2, int nti
         }
 }
 
+// ---- TN with LDS-DMA staging (full 128x128 tiles only) ---------------------------------------------
+// global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KiB contiguously into LDS, so the [32][128] chunk image
+// is filled row-pair by row-pair with no staging registers and no ds_write; two LDS buffers keep the next
+// chunk's DMA in flight under the current chunk's MFMAs with ONE barrier per chunk.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__global__ __launch_bounds__(256) void k_gemm_tn_dma(PnTnArgs g, int tiles2, int ntiles, int nsplit) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * BM];  // [buf][X|Y][32][128] = 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
+    const int tile = jj % ntiles;
+    const int64_t split = (int64_t)(jj / ntiles) * 8 + xcd;
+    if (split >= nsplit) return;
+    const int i0 = (tile / tiles2) * BM, j0 = (tile % tiles2) * BN;
+    const int64_t c_begin = split * (g.rows_per_split / BK);
+    int64_t c_end = c_begin + g.rows_per_split / BK;
+    if (c_end > g.chunks_total) c_end = g.chunks_total;
+
+    const float* const X0 = g.seg[0].X;
+    const float* const Y0 = g.seg[0].Y;
+    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
+    const int64_t M0 = g.seg[0].M;
+    const float* const X1 = g.seg[1].X;
+    const float* const Y1 = g.seg[1].Y;
+    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
+    const int64_t M1 = g.seg[1].M;
+    const int64_t chunks0 = g.chunks0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // each wave issues 4 X pieces + 4 Y pieces per chunk; piece p covers rows 2p, 2p+1 (lane -> row, 16-B column)
+    auto stage = [&](int64_t c, int buf) {
+        const bool s1 = c >= chunks0;
+        const float* X = s1 ? X1 : X0;
+        const float* Y = s1 ? Y1 : Y0;
+        const int ldx = s1 ? ldx1 : ldx0, ldy = s1 ? ldy1 : ldy0;
+        const int64_t Mseg = s1 ? M1 : M0;
+        const int64_t r0 = (s1 ? c - chunks0 : c) * BK;
+        float* xs = smem + buf * (2 * BK * BM);
+        float* ys = xs + BK * BM;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = wid * 4 + p;              // 0..15
+            const int row = piece * 2 + (lane >> 5);    // 0..31
+            int64_t gr = r0 + row;
+            gr = gr < Mseg ? gr : Mseg - 1;             // clamped; tail rows are zeroed after landing
+            const int col = (lane & 31) * 4;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(X + gr * ldx + i0 + col), (lds_ptr_t)(xs + piece * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Y + gr * ldy + j0 + col), (lds_ptr_t)(ys + piece * 256), 16, 0, 0);
+        }
+    };
+    auto valid_rows = [&](int64_t c) -> int {
+        const bool s1 = c >= chunks0;
+        const int64_t Mseg = s1 ? M1 : M0;
+        const int64_t r0 = (s1 ? c - chunks0 : c) * BK;
+        const int64_t v = Mseg - r0;
+        return v >= BK ? BK : (int)v;
+    };
+
+    if (c_begin < c_end) {
+        stage(c_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // one ds_read_b64 per operand and k-step: a lane takes columns 2i and 2i+1 of its wave's 64, i.e. MFMA
+        // tile tm covers the stride-2 column set {2i + tm} (the epilogue un-permutes)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int xo = (lane >> 5) * BM + wm * 64 + 2 * (lane & 31);
+        const int yo = (lane >> 5) * BM + wn * 64 + 2 * (lane & 31);
+        for (int64_t c = c_begin; c < c_end; ++c) {
+            const int buf = (int)((c - c_begin) & 1);
+            float* Xs = smem + buf * (2 * BK * BM);
+            float* Ys = Xs + BK * BM;
+            const int vr = valid_rows(c);
+            if (vr < BK) {  // ragged tail of a segment: zero the rows past the end (uniform branch)
+                for (int e = tid; e < (BK - vr) * BM; e += 256) {
+                    Xs[vr * BM + e] = 0.f;
+                    Ys[vr * BM + e] = 0.f;
+                }
+                __syncthreads();
+            }
+            if (c + 1 < c_end) stage(c + 1, buf ^ 1);
+            f32x2 a = *reinterpret_cast<const f32x2*>(Xs + xo);
+            f32x2 b = *reinterpret_cast<const f32x2*>(Ys + yo);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                f32x2 an = a, bn = b;
+                if (kk + 1 < BK / 2) {  // fetch the next k-step's operands before this step's MFMAs
+                    an = *reinterpret_cast<const f32x2*>(Xs + xo + (kk + 1) * 2 * BM);
+                    bn = *reinterpret_cast<const f32x2*>(Ys + yo + (kk + 1) * 2 * BM);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc[1][1], 0, 0, 0);
+                a = an;
+                b = bn;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's DMA has landed (this wave's part)
+            __syncthreads();
+        }
+    }
+    float* out = g.slab + split * (int64_t)g.N1 * g.N2;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = j0 + wn * 64 + 2 * (lane & 31) + tn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + tm;
+                out[(int64_t)row * g.N2 + col] = acc[tm][tn][r];
+            }
+        }
+}
+
 // Deterministic sum over a leading "partials" dimension: out[e] = sum_b src[b*stride + e'] for the
 // elements e of a [rows, cols] block.  One block = 64 elements x 4 partial lanes; grid.y splits the partials.
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols,
@@ -580,7 +736,9 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
         ProfScope prof(1, 2.0 * (double)Mtotal * N1 * N2, s);
         const int ntiles = tiles1 * tiles2;
         const int groups = (nsplit + 7) / 8;
-        hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
+        const bool full = (N1 % BM == 0) && (N2 % BN == 0) && !(g_dbg & 32);
+        if (full) hipLaunchKernelGGL(k_gemm_tn_dma, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
+        else hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
     }
     PN_CHECK_LAUNCH();
     return pn_launch_reduce_rows(work, nsplit, (int64_t)N1 * N2, N1, N2, N2, C, ldc, accumulate, nullptr, s);

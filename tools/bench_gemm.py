@@ -39,3 +39,17 @@ for blocks in (256, 512, 1024):
     ms = timeit(lambda: lib.call("pn_mfma_probe", out.data_ptr(), blocks, iters, st), n=5)
     fl = blocks * 4 * iters * 4 * 2 * 32 * 32 * 2
     print(f"mfma probe blocks={blocks:5d}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
+
+# leading-dimension experiment: power-of-two row pitch (1 KiB) vs padded pitches
+for ld in (256, 264, 272, 288, 320):
+    A2 = torch.randn(M, ld, device=dev); C2 = torch.empty(M, ld, device=dev)
+    ms = timeit(lambda: lib.call("pn_gemm_nt", M, 256, 256, A2.data_ptr(), ld, W.data_ptr(), 256, C2.data_ptr(), ld, bias.data_ptr(), None, 256, 0, st))
+    ms2 = timeit(lambda: lib.call("pn_gemm_nt", M, 256, 256, A2.data_ptr(), ld, W.data_ptr(), 256, C2.data_ptr(), ld, bias.data_ptr(), None, 256, 0x100, st))
+    print(f"nt plain lda=ldc={ld}: {ms*1e3:8.1f} us {2*M*256*256/ms/1e9:7.1f} TF   nostore {ms2*1e3:8.1f} us {2*M*256*256/ms2/1e9:7.1f} TF")
+    del A2, C2
+
+# weight row pitch experiment (every workgroup streams the same 256 KB weight matrix out of L2)
+for ldb in (256, 260, 264, 272, 288, 320):
+    W2 = torch.randn(256, ldb, device=dev) * 0.06
+    ms = timeit(lambda: lib.call("pn_gemm_nt", M, 256, 256, A.data_ptr(), 256, W2.data_ptr(), ldb, C.data_ptr(), 256, bias.data_ptr(), None, 256, 0, st))
+    print(f"nt plain ldb={ldb}: {ms*1e3:8.1f} us {2*M*256*256/ms/1e9:7.1f} TF")
