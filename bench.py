@@ -167,6 +167,23 @@ def main():
         _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
         prof[name] = (ms.value, n.value, fl.value)
     _lib.load().pn_prof_enable(0)
+    # the same kernels with the side stream off: per-launch durations without time-sharing (not part of `value`)
+    iso = {}
+    if rank == 0:
+        model.overlap_weight_grads = False
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        _lib.load().pn_prof_enable(1)
+        for i in range(2):
+            step(args.warmup + args.steps + 1 + i)
+        torch.cuda.synchronize()
+        for cls, name in ((0, "k_gemm_nt"), (1, "k_gemm_tn")):
+            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+            iso[name] = {"avg_launch_us": 1e3 * ms.value / max(n.value, 1), "tflops": fl.value / max(ms.value, 1e-9) / 1e9,
+                         "frac": fl.value / max(ms.value, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS}
+        _lib.load().pn_prof_enable(0)
+        model.overlap_weight_grads = True
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -200,6 +217,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "avg_launch_us": avg_us, "launches": n,
+                         "note": "timed region runs the weight-gradient GEMMs (k_gemm_tn) on a side stream, concurrently "
+                                 "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the same "
+                                 "kernels in 2 extra steps with the side stream off",
+                         "isolated": iso,
                          "flop_per_launch": fl / max(n, 1),
                          "other": {k: {"total_ms": v[0], "launches": v[1],
                                        "tflops": v[2] / max(v[0], 1e-9) / 1e9} for k, v in prof.items()},

@@ -132,14 +132,16 @@ int pn_density_grad(int64_t M, int num_density_channels, float density_bias, con
  *     path: needs rsweep from pn_density_grad; d_raw_density[:,0] receives the
  *     softplus'' term internally);
  *   d_mean [M,3] or null: if non-null receives d loss / d mean (first-order, env-light path).
- * work: scratch of pn_mlp_backward_work_floats(M, view_rows) floats. */
+ * work: scratch of pn_mlp_backward_work_floats(M, view_rows) floats.
+ * side_stream (nullable): a second hipStream_t; when given, the weight-gradient GEMMs / reductions run there,
+ * forked from and joined back to `stream` with events inside the call, so they overlap the data-gradient chain. */
 int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows);
 int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, float density_bias,
                     const float* params, const float* wpack, const float* mean, const float* cov,
                     const float* enc, const float* viewenc, const float* acts, const uint32_t* masks,
                     const float* raw_density, const float* d_raw_rgb, const float* d_raw_density,
                     const float* rsweep, const float* v_gradmean, float* d_mean, float* grads, float* work,
-                    void* stream);
+                    void* stream, void* side_stream);
 
 /* ---- volumetric rendering ---------------------------------------------------------
  * compute_graph activations (models/pano_mip_nerf.py:273-278) + volumetric_rendering

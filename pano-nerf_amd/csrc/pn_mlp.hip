@@ -15,6 +15,7 @@
 // balance), see DESIGN.md.
 #include "pn_common.h"
 #include <math.h>
+#include <vector>
 
 #define ST(s) ((hipStream_t)(s))
 #define RUN(x)                  \
@@ -204,6 +205,13 @@ __global__ __launch_bounds__(256) void k_colsum(int64_t M, int rows_per_block, c
     if (col < N) partial[(int64_t)blockIdx.x * N + col] = s;
 }
 
+struct BiasOffsets {
+    int64_t off[9];
+};
+__global__ void k_bias_scatter(const float* tmp, BiasOffsets bo, float* grads) {
+    grads[bo.off[blockIdx.x] + threadIdx.x] += tmp[blockIdx.x * PN_WIDTH + threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------ small fused bits
 // per-view-row bias of the view layer: vb[r][j] = bv[j] + sum_i viewenc[r][i] * Wv[j][256 + i]
 __global__ void k_view_bias(int64_t R, const float* viewenc, const float* Wv, const float* bv, float* vb) {
@@ -291,7 +299,7 @@ static int head_bwd_data(int64_t M, const float* d, int ldd, const float* W, flo
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
-#define HEAD_ROWS 512
+#define HEAD_ROWS 128
 // dW[NC][K] += sum coef * d^T x ; db[NC] += sum coef * d  (db may be null)
 template <int VEC, int NC>
 static int head_bwd_weight(int64_t M, const float* d, int ldd, const float* coef, const float* x, int ldx, float* dW,
@@ -306,7 +314,7 @@ static int head_bwd_weight(int64_t M, const float* d, int ldd, const float* coef
     if (db) RUN(pn_launch_reduce_rows(partial + NC * K, nb, NC * K + NC, 1, NC, NC, db, NC, 1, scratch, s));
     return PN_OK;
 }
-#define COLSUM_ROWS 256
+#define COLSUM_ROWS 64
 static int colsum_into(int64_t M, const float* X, int ldx, int N, float* dst, float* partial, hipStream_t s) {
     int nb = (int)nblk(M, COLSUM_ROWS);
     hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, M, COLSUM_ROWS, X, ldx, N, partial);
@@ -458,18 +466,33 @@ int pn_density_grad(int64_t M, int nc, float density_bias, const float* params, 
     return PN_OK;
 }
 
+// events for the fork/join between the data-gradient chain (main stream) and the weight-gradient work (side
+// stream); a small process-wide pool, re-recorded every call (graph-capturable fork/join pattern)
+static std::vector<hipEvent_t> g_events;
+struct EventRing {
+    size_t next = 0;
+    hipEvent_t get() {
+        if (next == g_events.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            g_events.push_back(e);
+        }
+        return g_events[next++];
+    }
+};
+
 int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows) {
     const int64_t Mp = pn_pad(M);
     int64_t n = 0;
-    n += 2 * Mp * PN_WIDTH;       // delta ping-pong
-    n += 2 * Mp * PN_WIDTH;       // tangent ping-pong
-    n += Mp * PN_WIDTH;           // head addend / d_bott
+    n += 9 * Mp * PN_WIDTH;       // delta_0..delta_7 (kept: the weight-gradient stream reads them) + head addend
+    n += 8 * Mp * PN_WIDTH;       // tangent hdot_0..hdot_7
+    n += Mp * PN_WIDTH;           // d_bott
     n += Mp * PN_WIDTH_COND;      // d view hidden
     n += 2 * Mp * PN_ENC_DIM;     // edot, d_enc
     n += Mp * 32;                 // expanded viewenc
     n += Mp * 8 + Mp * 2;         // dden copy, sdot, coef
     n += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);  // slabs
-    n += (Mp / 64) * PN_WIDTH + 64 * PN_WIDTH;           // epilogue column sums + reduce scratch
+    n += 9 * (Mp / 64) * PN_WIDTH + 64 * 9 * PN_WIDTH + 9 * PN_WIDTH;  // epilogue column sums + reduce scratch
     int64_t nb = (M + HEAD_ROWS - 1) / HEAD_ROWS;
     int64_t hp = nb * (5 * PN_WIDTH + 5) + 64 * (5 * PN_WIDTH + 5);
     int64_t cp = ((M + COLSUM_ROWS - 1) / COLSUM_ROWS) * PN_WIDTH + 64 * PN_WIDTH;
@@ -482,7 +505,7 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
                     const float* wpack, const float* mean, const float* cov, const float* enc, const float* viewenc,
                     const float* acts, const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
                     const float* d_raw_density, const float* rsweep, const float* v_gradmean, float* d_mean,
-                    float* grads, float* work, void* stream) {
+                    float* grads, float* work, void* stream, void* side_stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     if (!params || !wpack || !mean || !cov || !enc || !viewenc || !acts || !masks || !raw_density || !d_raw_rgb ||
@@ -490,17 +513,29 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         return PN_ERR_NULL;
     if (v_gradmean && !rsweep) return PN_ERR_NULL;
     hipStream_t s = ST(stream);
+    // ws: the stream every "accumulate into grads" kernel runs on (in order, so they never race each other).
+    // With a side stream the weight-gradient GEMMs fill the MFMA slots the data-gradient chain leaves idle.
+    hipStream_t ws = side_stream ? ST(side_stream) : s;
+    const bool forked = ws != s;
+    EventRing ring;
+    auto hand_off = [&]() -> int {  // everything enqueued on `s` so far is visible to later work on `ws`
+        if (!forked) return PN_OK;
+        hipEvent_t e = ring.get();
+        if (!e || hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(ws, e, 0) != hipSuccess) return PN_ERR_HIP;
+        return PN_OK;
+    };
     PnLayout L = pn_layout(nc);
     PnPack P = pn_pack_layout();
     const int64_t Mp = pn_pad(M);
     auto act = [&](int i) { return acts + (int64_t)i * Mp * PN_WIDTH; };
     auto rs = [&](int i) { return rsweep + (int64_t)i * Mp * PN_WIDTH; };
+    auto mask = [&](int i) { return masks + (int64_t)i * Mp * PN_MASK_WORDS; };
     // carve the workspace (every piece is a multiple of 4 floats -> 16-B aligned if `work` is)
     float* w = work;
-    float* delta[2] = {w, w + Mp * PN_WIDTH};
-    w += 2 * Mp * PN_WIDTH;
-    float* tang[2] = {w, w + Mp * PN_WIDTH};
-    w += 2 * Mp * PN_WIDTH;
+    float* dbuf = w; w += 9 * Mp * PN_WIDTH;
+    auto delta = [&](int l) { return dbuf + (int64_t)l * Mp * PN_WIDTH; };  // l = 0..7; 8 = head addend
+    float* tbuf = w; w += 8 * Mp * PN_WIDTH;
+    auto tang = [&](int l) { return tbuf + (int64_t)l * Mp * PN_WIDTH; };
     float* dbott = w; w += Mp * PN_WIDTH;
     float* dvh = w; w += Mp * PN_WIDTH_COND;
     float* edot = w; w += Mp * PN_ENC_DIM;
@@ -510,32 +545,33 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     float* sdot = w; w += Mp;
     float* coef = w; w += Mp;
     float* slab = w; w += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);
-    float* csum = w; w += (Mp / 64) * PN_WIDTH;   // per-wave column sums written by the GEMM epilogues
-    float* csum_scratch = w; w += 64 * PN_WIDTH;
+    float* csum = w; w += 9 * (Mp / 64) * PN_WIDTH;   // [9 biases][row partials][256] from the GEMM epilogues
+    float* csum_scratch = w; w += 64 * 9 * PN_WIDTH + 9 * PN_WIDTH;
     float* partial = w;
-    auto mask = [&](int i) { return masks + (int64_t)i * Mp * PN_MASK_WORDS; };
     const int64_t csum_rows = 2 * ((M + 127) / 128);
-    auto bias_grad = [&](int64_t off) {
-        return pn_launch_reduce_rows(csum, csum_rows, PN_WIDTH, 1, PN_WIDTH, PN_WIDTH, grads + off, PN_WIDTH, 1,
-                                     csum_scratch, s);
-    };
+    auto csum_slot = [&](int slot) { return csum + (int64_t)slot * csum_rows * PN_WIDTH; };
     const int ld5 = PN_WIDTH + PN_ENC_DIM;
     const int ldv = PN_WIDTH + PN_VIEW_DIM;
 
+    RUN(hand_off());  // inputs produced earlier on the main stream
+    // colour-head weight gradient only needs inputs: start the side stream with it
+    RUN((head_bwd_weight<2, 3>(M, d_raw_rgb, 3, nullptr, act(9), PN_WIDTH, grads + L.wc, grads + L.bc, partial, ws)));
+
     const float* dden_use = d_raw_density;
-    // ---------------- second-order path: tangent sweep + its weight gradients -----------------
+    // ---------------- second-order path: tangent sweep (main) + its weight gradients (ws) -----------
     if (v_gradmean) {
         RUN(pn_launch_ipe_tangent(M, mean, cov, v_gradmean, edot, s));
+        RUN(hand_off());
         const float* prev = edot;
         int prev_ld = PN_ENC_DIM;
         for (int l = 0; l < 8; ++l) {
             // dW_l += r_l^T * hdot_{l-1}   (layer 5 also against edot for the skip columns)
             int kin = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
             int ldw = (l == 0) ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH);
-            RUN(wgrad(M, rs(l), PN_WIDTH, PN_WIDTH, prev, prev_ld, kin, grads + L.w[l], ldw, slab, s));
-            if (l == 5) RUN(wgrad(M, rs(5), PN_WIDTH, PN_WIDTH, edot, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, s));
-            // hdot_l = [h_l > 0] * (hdot_{l-1} * W_l^T)
-            float* cur = tang[l & 1];
+            RUN(wgrad(M, rs(l), PN_WIDTH, PN_WIDTH, prev, prev_ld, kin, grads + L.w[l], ldw, slab, ws));
+            if (l == 5) RUN(wgrad(M, rs(5), PN_WIDTH, PN_WIDTH, edot, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, ws));
+            // hdot_l = gate_l * (hdot_{l-1} * W_l^T)
+            float* cur = tang(l);
             PnGemmNt g;
             if (l == 0) {
                 g = nt(M, PN_WIDTH, edot, PN_ENC_DIM, params + L.w[0], PN_ENC_DIM, PN_ENC_DIM, cur, PN_WIDTH);
@@ -548,6 +584,7 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
             g.gate_bits = mask(l);
             g.flags = PN_EPI_GATEBITS;
             RUN(pn_launch_gemm_nt(g, s));
+            RUN(hand_off());
             prev = cur;
             prev_ld = PN_WIDTH;
         }
@@ -556,85 +593,85 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         hipLaunchKernelGGL(k_second_order_seed, dim3(nblk(M * nc, 256)), dim3(256), 0, s, M, nc, density_bias,
                            raw_density, sdot, d_raw_density, dden, coef);
         PN_CHECK_LAUNCH();
+        RUN(hand_off());
         dden_use = dden;
-        // x = hdot_7, d = ones scaled by coef: reuse head_bwd_weight with d = coef as a 1-channel "gradient"
-        RUN((head_bwd_weight<4, 1>(M, coef, 1, nullptr, prev, PN_WIDTH, grads + L.wd, nullptr, partial, s)));
+        RUN((head_bwd_weight<4, 1>(M, coef, 1, nullptr, prev, PN_WIDTH, grads + L.wd, nullptr, partial, ws)));
     }
 
     // ---------------- colour head + view layer ------------------------------------------------
-    RUN((head_bwd_weight<2, 3>(M, d_raw_rgb, 3, nullptr, act(9), PN_WIDTH, grads + L.wc, grads + L.bc, partial, s)));
     RUN((head_bwd_data<2, 3>(M, d_raw_rgb, 3, params + L.wc, dvh, PN_WIDTH_COND, act(9), PN_WIDTH, s)));
-    RUN(wgrad(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, act(8), PN_WIDTH, PN_WIDTH, grads + L.wv, ldv, slab, s));
-    hipLaunchKernelGGL(k_expand_viewenc, dim3(nblk(M * 32, 256)), dim3(256), 0, s, M, rows_per_ray, view_rows, viewenc,
+    RUN(hand_off());
+    RUN(wgrad(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, act(8), PN_WIDTH, PN_WIDTH, grads + L.wv, ldv, slab, ws));
+    hipLaunchKernelGGL(k_expand_viewenc, dim3(nblk(M * 32, 256)), dim3(256), 0, ws, M, rows_per_ray, view_rows, viewenc,
                        VE);
     PN_CHECK_LAUNCH();
     {
         PnSegTn sg{dvh, VE, PN_WIDTH_COND, 32, M};
         // [128][32] product; only the first 27 columns exist in the parameter: land it in scratch, then add
         float* tmp = partial;  // 128*32 floats
-        RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, tmp, 32, 0, slab, s));
-        RUN(pn_launch_reduce_rows(tmp, 1, 0, PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv, 1, nullptr, s));
+        RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, tmp, 32, 0, slab, ws));
+        RUN(pn_launch_reduce_rows(tmp, 1, 0, PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv, 1, nullptr, ws));
     }
-    RUN(colsum_into(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv, partial, s));
+    RUN(colsum_into(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv, partial, ws));
     {  // d bottleneck = dvh * Wv[:, :256]
         PnGemmNt g = nt(M, PN_WIDTH, dvh, PN_WIDTH_COND, wpack + P.wvm_t, PN_WIDTH_COND, PN_WIDTH_COND, dbott, PN_WIDTH);
-        g.colsum = csum;
+        g.colsum = csum_slot(0);
         g.flags = PN_EPI_COLSUM;
         RUN(pn_launch_gemm_nt(g, s));
     }
-    RUN(bias_grad(L.be));
-    RUN(wgrad(M, dbott, PN_WIDTH, PN_WIDTH, act(7), PN_WIDTH, PN_WIDTH, grads + L.we, PN_WIDTH, slab, s));
     // ---------------- density head ----------------------------------------------------------
-    float* d7 = delta[1];
-    if (nc == 5) {
-        RUN((head_bwd_weight<4, 5>(M, dden_use, 5, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, s)));
-        RUN((head_bwd_data<4, 5>(M, dden_use, 5, params + L.wd, delta[0], PN_WIDTH, nullptr, 0, s)));
-    } else {
-        RUN((head_bwd_weight<4, 1>(M, dden_use, 1, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, s)));
-        RUN((head_bwd_data<4, 1>(M, dden_use, 1, params + L.wd, delta[0], PN_WIDTH, nullptr, 0, s)));
-    }
-    {  // delta_7 = [h7 > 0] * (d_bott * We + d_raw_density * Wd)
-        PnGemmNt g = nt(M, PN_WIDTH, dbott, PN_WIDTH, wpack + P.we_t, PN_WIDTH, PN_WIDTH, d7, PN_WIDTH);
-        g.addc = delta[0];
+    if (nc == 5) RUN((head_bwd_data<4, 5>(M, dden_use, 5, params + L.wd, delta(8), PN_WIDTH, nullptr, 0, s)));
+    else RUN((head_bwd_data<4, 1>(M, dden_use, 1, params + L.wd, delta(8), PN_WIDTH, nullptr, 0, s)));
+    RUN(hand_off());
+    RUN(wgrad(M, dbott, PN_WIDTH, PN_WIDTH, act(7), PN_WIDTH, PN_WIDTH, grads + L.we, PN_WIDTH, slab, ws));
+    if (nc == 5) RUN((head_bwd_weight<4, 5>(M, dden_use, 5, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, ws)));
+    else RUN((head_bwd_weight<4, 1>(M, dden_use, 1, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, ws)));
+    {  // delta_7 = gate_7 * (d_bott * We + d_raw_density * Wd)
+        PnGemmNt g = nt(M, PN_WIDTH, dbott, PN_WIDTH, wpack + P.we_t, PN_WIDTH, PN_WIDTH, delta(7), PN_WIDTH);
+        g.addc = delta(8);
         g.ldadd = PN_WIDTH;
         g.gate_bits = mask(7);
-        g.colsum = csum;
+        g.colsum = csum_slot(1);
         g.flags = PN_EPI_ADDC | PN_EPI_GATEBITS | PN_EPI_COLSUM;
         RUN(pn_launch_gemm_nt(g, s));
     }
-    RUN(bias_grad(L.b[7]));
     // ---------------- trunk ---------------------------------------------------------------------
-    float* cur = d7;
-    float* d5 = nullptr;
     for (int l = 7; l >= 0; --l) {
+        RUN(hand_off());  // delta_l is complete on the main stream
         const float* xin = (l == 0) ? enc : act(l - 1);
         int ldx = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
         int kin = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
         int ldw = (l == 0) ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH);
-        RUN(wgrad(M, cur, PN_WIDTH, PN_WIDTH, xin, ldx, kin, grads + L.w[l], ldw, slab, s));
-        if (l == 5) RUN(wgrad(M, cur, PN_WIDTH, PN_WIDTH, enc, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, s));
-        if (l == 5 && d_mean) {
-            // keep delta_5 alive for the d_enc GEMM: park it in the tangent buffer (free by now)
-            if (hipMemcpyAsync(tang[0], cur, sizeof(float) * M * PN_WIDTH, hipMemcpyDeviceToDevice, s) != hipSuccess)
-                return PN_ERR_HIP;
-            d5 = tang[0];
-        }
+        RUN(wgrad(M, delta(l), PN_WIDTH, PN_WIDTH, xin, ldx, kin, grads + L.w[l], ldw, slab, ws));
+        if (l == 5) RUN(wgrad(M, delta(5), PN_WIDTH, PN_WIDTH, enc, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, ws));
         if (l > 0) {
-            float* nxt = (cur == delta[0]) ? delta[1] : delta[0];
-            PnGemmNt g = nt(M, PN_WIDTH, cur, PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, nxt, PN_WIDTH);
+            PnGemmNt g = nt(M, PN_WIDTH, delta(l), PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, delta(l - 1), PN_WIDTH);
             g.gate_bits = mask(l - 1);
-            g.colsum = csum;
+            g.colsum = csum_slot(1 + (7 - (l - 1)));
             g.flags = PN_EPI_GATEBITS | PN_EPI_COLSUM;
             RUN(pn_launch_gemm_nt(g, s));
-            RUN(bias_grad(L.b[l - 1]));
-            cur = nxt;
         }
     }
+    {  // bias gradients: one reduction over the nine column-sum slots (slot 0: extra, slot 1 + (7 - l): layer l)
+        RUN(hand_off());
+        float* tmp = csum_scratch + 64 * 9 * PN_WIDTH;
+        RUN(pn_launch_reduce_rows(csum, csum_rows, PN_WIDTH, 9, PN_WIDTH, (int)(csum_rows * PN_WIDTH), tmp, PN_WIDTH, 0,
+                                  csum_scratch, ws));
+        BiasOffsets bo;
+        bo.off[0] = L.be;
+        for (int l = 0; l < 8; ++l) bo.off[1 + (7 - l)] = L.b[l];
+        hipLaunchKernelGGL(k_bias_scatter, dim3(9), dim3(256), 0, ws, tmp, bo, grads);
+        PN_CHECK_LAUNCH();
+    }
     if (d_mean) {  // d enc = delta_0 * W_0 + delta_5 * W_5[:, 256:]  ->  d mean
-        PnGemmNt g = nt(M, PN_ENC_DIM, cur, PN_WIDTH, wpack + P.wt[0], PN_WIDTH, PN_WIDTH, denc, PN_ENC_DIM);
-        seg2(g, d5, PN_WIDTH, wpack + P.w5e_t, PN_WIDTH, PN_WIDTH);
+        PnGemmNt g = nt(M, PN_ENC_DIM, delta(0), PN_WIDTH, wpack + P.wt[0], PN_WIDTH, PN_WIDTH, denc, PN_ENC_DIM);
+        seg2(g, delta(5), PN_WIDTH, wpack + P.w5e_t, PN_WIDTH, PN_WIDTH);
         RUN(pn_launch_gemm_nt(g, s));
         RUN(pn_launch_ipe_backward(M, mean, cov, denc, d_mean, s));
+    }
+    if (forked) {  // join: later work on the main stream sees the finished gradients
+        hipEvent_t e = ring.get();
+        if (!e || hipEventRecord(e, ws) != hipSuccess || hipStreamWaitEvent(s, e, 0) != hipSuccess) return PN_ERR_HIP;
     }
     return PN_OK;
 }

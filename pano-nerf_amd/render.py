@@ -74,13 +74,25 @@ def _composite_backward(ev, R, N, cfg, white, dirs, dir_mod, d_comp, d_dist, d_w
               d_comp.data_ptr(), _lib.ptr(d_dist), _lib.ptr(d_w), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(), st)
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """Second HIP stream per device for the weight-gradient work (forked/joined inside pn_mlp_backward)."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 def _mlp_backward(ev, cfg, params, wpack, d_raw_rgb, d_raw_den, v, d_mean, flat_grad, st):
     n = int(_lib.load().pn_mlp_backward_work_floats(ev.M, ev.view_rows))
     work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
     _lib.call("pn_mlp_backward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, cfg.density_bias, params.data_ptr(),
               wpack.data_ptr(), ev.mean.data_ptr(), ev.cov.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
               ev.acts.data_ptr(), ev.masks.data_ptr(), ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(),
-              _lib.ptr(ev.rsweep), _lib.ptr(v), _lib.ptr(d_mean), flat_grad.data_ptr(), work.data_ptr(), st)
+              _lib.ptr(ev.rsweep), _lib.ptr(v), _lib.ptr(d_mean), flat_grad.data_ptr(), work.data_ptr(), st,
+              _side_stream(flat_grad.device).cuda_stream if cfg.overlap else None)
 
 
 class _RenderFn(torch.autograd.Function):
@@ -251,6 +263,7 @@ class _RenderBase(torch.nn.Module):
         if self.mlp.num_density_channels != self._NC:
             raise NotImplementedError(f"{type(self).__name__} needs mlp_num_density_channels={self._NC}")
         self.noise_override = None  # tests: dict(t_rand=[B,S], u_rand=[B,S], env_rand=[1,Ne+1])
+        self.overlap_weight_grads = True  # weight-gradient GEMMs on a side stream (same results, different order of launch)
 
     def _noise(self, randomized, B, dev, want_env):
         if not randomized:
@@ -280,7 +293,7 @@ class _RenderBase(torch.nn.Module):
         cfg = _Cfg(num_samples=self.num_samples, nc=self._NC, density_bias=self.density_bias,
                    rgb_padding=self.rgb_padding, resample_padding=self.resample_padding,
                    white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
-                   num_env_samples=self.num_env_samples)
+                   num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads)
         plist = [p for _, p in self.mlp.named_in_order()]
         outs = _RenderFn.apply(cfg, self.mlp, o, d, vd, radii, near, far, *env, t_rand, u_rand,
                                None if env_rand is None else env_rand.reshape(-1), *plist)
