@@ -6,6 +6,7 @@ Public surface (mirrors the reference's names):
     generate_pano_rays, generate_lit_rays   datasets/pano_datasets.py:152-263
     pano_loss, mip_loss           systems/panonerf_system.py:15-75, systems/mipnerf_system.py:22-53
     FlatAdam, mip_lr              systems/base_system.py:82-87, utils/lr_schedule.py:51-59
+    render_image                  systems/panonerf_system.py:133-192
 """
 __version__ = "0.1.0"
 
@@ -13,3 +14,4 @@ from .rays import Rays, Rays_keys, namedtuple_map, rearrange_render_image, gener
 from .render import PanoMipNeRF, MipNeRF  # noqa
 from .loss import pano_loss, mip_loss  # noqa
 from .optim import FlatAdam, mip_lr  # noqa
+from .renderer import render_image  # noqa

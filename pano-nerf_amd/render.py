@@ -113,6 +113,7 @@ class _RenderFn(torch.autograd.Function):
             B, N, nc = o.shape[0], cfg.num_samples, cfg.nc
             S, M = N + 1, o.shape[0] * cfg.num_samples
             e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            keep = cfg.keep  # inference (no_grad): release the big activation buffers as soon as possible
             # ---- level 0: stratified samples
             e0 = _Eval(M, N, vd, nc, dev)
             e0.t = e(B, S)
@@ -120,6 +121,8 @@ class _RenderFn(torch.autograd.Function):
                       far.data_ptr(), _lib.ptr(t_rand), e0.t.data_ptr(), e0.mean.data_ptr(), e0.cov.data_ptr(), st)
             _mlp_forward(e0, params, wpack, st)
             comp0, dist0, _, w0 = _composite_forward(e0, B, N, cfg, cfg.white_bkgd, d, B, st)
+            if not keep:
+                e0.acts = e0.masks = e0.enc = None
             # ---- level 1: PDF resample (no gradient through the weights: stop_resample_grad)
             e1 = _Eval(M, N, vd, nc, dev)
             e1.t = e(B, S)
@@ -144,6 +147,11 @@ class _RenderFn(torch.autograd.Function):
                           d.data_ptr(), normal.data_ptr(), _lib.ptr(ort_ray), _lib.ptr(albedo), st)
                 if cfg.use_ort:
                     ort = ort_ray.mean()
+                if not keep:
+                    e1.rsweep = None
+                    del scratch
+            if not keep:
+                e1.acts = e1.masks = e1.enc = None
             if cfg.surf:
                 D, Ne = env_d.shape[0], cfg.num_env_samples
                 ee = _Eval(B * D * Ne, Ne, env_d, nc, dev)
@@ -293,7 +301,8 @@ class _RenderBase(torch.nn.Module):
         cfg = _Cfg(num_samples=self.num_samples, nc=self._NC, density_bias=self.density_bias,
                    rgb_padding=self.rgb_padding, resample_padding=self.resample_padding,
                    white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
-                   num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads)
+                   num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads,
+                   keep=torch.is_grad_enabled() and any(p.requires_grad for p in self.mlp.parameters()))
         plist = [p for _, p in self.mlp.named_in_order()]
         outs = _RenderFn.apply(cfg, self.mlp, o, d, vd, radii, near, far, *env, t_rand, u_rand,
                                None if env_rand is None else env_rand.reshape(-1), *plist)

@@ -1,0 +1,52 @@
+"""Chunked full-image render.
+
+Mirrors ``PanoNeRFSystem.render_image`` (systems/panonerf_system.py:133-192): flatten the H x W rays, slice
+them with ``rearrange_render_image`` (models/mip.py:530-547), render every chunk with ``randomized=False,
+enable_surf=True, use_ort_loss=True`` under no_grad, concatenate and reshape to ``[1, C, H, W]``.  The
+reference's ``val.chunk_size`` is 512 (1 024 Python iterations per 512x1024 panorama, sized for a 2020 GPU's
+memory); with 288 GB of HBM a chunk of 32 768 rays fits comfortably, so ``chunk_size`` defaults to that.
+With ``world > 1`` chunks are dealt round-robin to the ranks and gathered (SURVEY.md 8e 'Inference').
+"""
+import torch
+
+from .rays import Rays, rearrange_render_image
+
+_KEYS = ("coarse_rgb", "fine_rgb", "coarse_dep", "fine_dep", "fine_nor", "albedo", "roughness", "surface_rgb", "shading")
+
+
+def render_image(model, rays, env_rays, height, width, chunk_size=32768, white_bkgd=False, rank=0, world=1):
+    """rays: Rays of [1, H, W, C] (or [H*W, C]) device tensors.  Returns the 9-tuple of render_image:
+    (coarse_rgb, fine_rgb, coarse_dep, fine_dep, fine_nor, albedo, roughness(None), surface_rgb, shading), each
+    [1, C, H, W]."""
+    flat = Rays(*[x.reshape(-1, x.shape[-1]) for x in rays])
+    chunks, _ = rearrange_render_image(flat, chunk_size)
+    outs = {k: [] for k in ("coarse_rgb", "fine_rgb", "coarse_dep", "fine_dep", "fine_nor", "albedo", "surface_rgb", "shading")}
+    mine = range(rank, len(chunks), world)
+    with torch.no_grad():
+        for i in mine:
+            (c_rgb, c_dep, *_), (f_rgb, f_dep, _, f_nor, alb, _, sf_rgb, _, sd) = model(
+                rays=chunks[i], env_rays=env_rays, randomized=False, white_bkgd=white_bkgd, enable_surf=True,
+                use_ort_loss=True)
+            for k, v in zip(outs, (c_rgb, f_rgb, c_dep.view(-1, 1), f_dep.view(-1, 1), f_nor, alb, sf_rgb, sd)):
+                outs[k].append(v)
+    cat = {k: torch.cat(v, 0) if v else None for k, v in outs.items()}
+    if world > 1:
+        import torch.distributed as dist
+        from .dist import gather_image
+        packed = torch.cat([cat[k] for k in outs], 1)  # [n_local, 20]
+        allp = gather_image(packed, world)
+        # undo the round-robin dealing: rank r holds chunks r, r+world, ...
+        sizes = [chunks[i].origins.shape[0] for i in range(len(chunks))]
+        order, pos = [], 0
+        starts = {}
+        for r in range(world):
+            for i in range(r, len(chunks), world):
+                starts[i] = pos
+                pos += sizes[i]
+        full = torch.cat([allp[starts[i]:starts[i] + sizes[i]] for i in range(len(chunks))], 0)
+        widths = [cat[k].shape[1] for k in outs]
+        cols = torch.split(full, widths, 1)
+        cat = dict(zip(outs, cols))
+    img = lambda x: None if x is None else x.reshape(1, height, width, -1).permute(0, 3, 1, 2)
+    return (img(cat["coarse_rgb"]), img(cat["fine_rgb"]), img(cat["coarse_dep"]), img(cat["fine_dep"]), img(cat["fine_nor"]),
+            img(cat["albedo"]), None, img(cat["surface_rgb"]), img(cat["shading"]))

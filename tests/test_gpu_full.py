@@ -165,6 +165,25 @@ def test_render_image_chunks(golden):
             assert e < 1e-4, (k, e)
 
 
+def test_render_image_helper_matches_chunk_loop(golden):
+    """pano_nerf_amd.render_image with a different chunk size gives the same image as the reference's 32-ray loop."""
+    import pano_nerf_amd as pn
+    g = golden("render_image_8x16")
+    rg = golden("raygen_8x16")
+    rays = pn.generate_pano_rays(8, 16, rg["c2ws"][0])
+    env = pn.generate_lit_rays(10, pn.rays.pano_pixel_radius(rays))
+    model = make_pano(32)
+    out = pn.render_image(model, pn.Rays(*[x.view(1, 8, 16, -1) for x in rays]), env, 8, 16, chunk_size=48)
+    names = ("coarse_rgb", "fine_rgb", "coarse_dep", "fine_dep", "normal", "albedo", None, "surface_rgb", "shading")
+    for k, v in zip(names, out):
+        if k is None:
+            assert v is None
+            continue
+        assert v.shape[0] == 1 and v.shape[2:] == (8, 16)
+        e = rel_err(v.cpu().numpy(), g[k])
+        assert e < (5e-2 if k in ("normal", "surface_rgb", "shading") else 1e-4), (k, e)
+
+
 def test_bench_size_properties():
     """At the bench configuration (B=512, N=128) the oracle is too slow for a full compare; check
     size-independent properties: weights are a sub-probability, compositing is linear in colour,
