@@ -98,6 +98,8 @@ extern "C" int pn_prof_read(int cls, double* total_ms, int64_t* launches, double
 #define LDT (BK + 4)   // NT tiles: [128][36] floats; +4 keeps 16-B alignment and is conflict-free for b128
 #define LDX (BM + 4)   // TN tiles: [32][132] floats
 #define EPL 68         // epilogue transposition rows: 64 + 4 floats
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // blocks b and b+8 share an XCD: give each XCD a contiguous range of tiles (bijective form).
@@ -143,6 +145,94 @@ __device__ __forceinline__ void nt_store(float* As, float* Bs, int tid, const Nt
         int row = idx >> 3, c4 = idx & 7;
         *reinterpret_cast<f32x4*>(As + row * LDT + c4 * 4) = r.a[i];
         *reinterpret_cast<f32x4*>(Bs + row * LDT + c4 * 4) = r.b[i];
+    }
+}
+
+// Shared epilogue of the NT kernels (see the comment inside).  `smem` is the (now idle) staging LDS, at least
+// 4 * 32 * EPL floats.
+__device__ __forceinline__ void nt_epilogue(const PnGemmNt& g, f32x16 (&acc)[2][2], float* smem, int64_t m0, int n0,
+                                            int lane, int wid, int wm, int wn) {
+    // ---- epilogue.  The accumulators hold one column per lane (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), so a
+    // direct store is 64 dword stores per lane, each touching two 128-B row segments.  Instead every wave
+    // transposes its 32x64 half-tile through the (now free) staging LDS and streams full 256-B row segments
+    // as float4; bias / per-ray bias / addend / ReLU / gate / mask bits / column sums are applied there.
+    const int flags = g.flags;
+    float* Ls = smem + wid * (32 * EPL);
+    const int col4 = (lane & 15) * 4;  // column of this lane's float4 inside the wave's 64 columns
+    const int gcol = n0 + wn * 64 + col4;
+    const bool col_ok = gcol < g.N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if ((flags & PN_EPI_BIAS) && col_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + gcol);
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();  // every wave is done reading As / Bs
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ls[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPL + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lrow = (lane >> 4) + 4 * i;
+            const int64_t row = m0 + wm * 64 + tm * 32 + lrow;
+            const bool ok = col_ok && row < g.M;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ls + lrow * EPL + col4);
+            v += bias4;
+            if (ok) {
+                if (flags & PN_EPI_ROWBIAS) {
+                    int64_t ray = row / g.rows_per_ray;
+                    if (g.rb_mod > 0) ray %= g.rb_mod;
+                    v += *reinterpret_cast<const f32x4*>(g.rowbias + ray * g.ldrb + gcol);
+                }
+                if (flags & PN_EPI_ADDC) v += *reinterpret_cast<const f32x4*>(g.addc + row * g.ldadd + gcol);
+            }
+            if (flags & PN_EPI_RELU) {
+                v[0] = fmaxf(v[0], 0.f);
+                v[1] = fmaxf(v[1], 0.f);
+                v[2] = fmaxf(v[2], 0.f);
+                v[3] = fmaxf(v[3], 0.f);
+            }
+            if ((flags & PN_EPI_GATE) && ok) {
+                f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + row * g.ldg + gcol);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = gt[c] > 0.f ? v[c] : 0.f;
+            }
+            if ((flags & PN_EPI_GATEBITS) && ok) {
+                uint32_t w = g.gate_bits[row * PN_MASK_WORDS + (gcol >> 5)];
+                const int bi = (gcol >> 2) & 7;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = ((w >> (c * 8 + bi)) & 1u) ? v[c] : 0.f;
+            }
+            if (flags & PN_EPI_MASKOUT) {  // all 64 lanes take part in the ballots
+                uint32_t word = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned long long b = __ballot(v[c] > 0.f);
+                    word |= (uint32_t)((b >> ((lane >> 3) * 8)) & 0xffull) << (c * 8);
+                }
+                if (ok && (lane & 7) == 0) g.mask_out[row * PN_MASK_WORDS + (gcol >> 5)] = word;
+            }
+            if (ok) {
+                if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + gcol) = v;
+                csum += v;
+            }
+        }
+        __syncthreads();
+    }
+    if (flags & PN_EPI_COLSUM) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = csum[c];
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            csum[c] = x;
+        }
+        if (lane < 16 && col_ok) {
+            const int64_t prow = (m0 / 64) + wm;
+            *reinterpret_cast<f32x4*>(g.colsum + prow * g.N + gcol) = csum;
+        }
     }
 }
 
@@ -257,88 +347,96 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
     }
 #endif
 
-    // ---- epilogue.  The accumulators hold one column per lane (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), so a
-    // direct store is 64 dword stores per lane, each touching two 128-B row segments.  Instead every wave
-    // transposes its 32x64 half-tile through the (now free) staging LDS and streams full 256-B row segments
-    // as float4; bias / per-ray bias / addend / ReLU / gate / mask bits / column sums are applied there.
-    const int flags = g.flags;
-    float* Ls = smem + wid * (32 * EPL);
-    const int col4 = (lane & 15) * 4;  // column of this lane's float4 inside the wave's 64 columns
-    const int gcol = n0 + wn * 64 + col4;
-    const bool col_ok = gcol < g.N;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if ((flags & PN_EPI_BIAS) && col_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + gcol);
-    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    __syncthreads();  // every wave is done reading As / Bs
+    nt_epilogue(g, acc, smem, m0, n0, lane, wid, wm, wn);
+}
+
+// ---- NT with LDS-DMA staging ------------------------------------------------------------------------
+// K-chunks of 16 floats (64-B rows).  global_load_lds_dwordx4 fills LDS lane-linearly (64 lanes x 16 B = 16 rows
+// per wave-instruction), so the bank-conflict swizzle goes on the per-lane SOURCE address: LDS slot q' of row r
+// holds the 16-B k-piece q = q' ^ ((r >> 2) & 3), and the fragment reads apply the same XOR.  Two LDS buffers,
+// the next chunk's DMA in flight under the current chunk's 32 MFMAs, ONE barrier per chunk, no staging VGPRs.
+#define DK 16
+__global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 32 * EPL];  // 34 816 B >= 2 buffers x (A + B) x 128 x 16 floats
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nc0 = g.seg[0].K / DK;
+    const int nc1 = (g.nseg > 1) ? g.seg[1].K / DK : 0;
+    const int nchunks = nc0 + nc1;
+    const float* const A0 = g.seg[0].A;
+    const float* const B0 = g.seg[0].B;
+    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb;
+    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
+    const float* const B1 = g.nseg > 1 ? g.seg[1].B : B0;
+    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int64_t m0 = (int64_t)(t / tiles_n) * BM;
+    const int n0 = (t % tiles_n) * BN;
+
+    // staging: wave w moves rows 32w .. 32w+31 of A and of B (two 16-row pieces each)
+    const int srow = (lane >> 2);                     // row inside a 16-row piece
+    int64_t arow0 = m0 + wid * 32 + srow, arow1 = arow0 + 16;
+    arow0 = arow0 < g.M ? arow0 : g.M - 1;
+    arow1 = arow1 < g.M ? arow1 : g.M - 1;
+    int brow0 = n0 + wid * 32 + srow, brow1 = brow0 + 16;
+    brow0 = brow0 < g.N ? brow0 : g.N - 1;
+    brow1 = brow1 < g.N ? brow1 : g.N - 1;
+    // slot q' = lane & 3 of row r holds source piece q = q' ^ ((r >> 2) & 3); r = (wid*32 + piece*16 + srow)
+    const int q0 = (lane & 3) ^ ((srow >> 2) & 3);    // same for both pieces: (16 >> 2) & 3 == 0
+    auto stage = [&](int c, int buf) {
+        const bool s1 = c >= nc0;
+        const float* A = s1 ? A1 : A0;
+        const float* B = s1 ? B1 : B0;
+        const int lda = s1 ? lda1 : lda0, ldb = s1 ? ldb1 : ldb0;
+        const int k0 = (s1 ? c - nc0 : c) * DK + q0 * 4;
+        float* as = smem + buf * (2 * BM * DK);
+        float* bs = as + BM * DK;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + arow0 * lda + k0), (lds_ptr_t)(as + (wid * 32) * DK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + arow1 * lda + k0), (lds_ptr_t)(as + (wid * 32 + 16) * DK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(B + (int64_t)brow0 * ldb + k0), (lds_ptr_t)(bs + (wid * 32) * DK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(B + (int64_t)brow1 * ldb + k0), (lds_ptr_t)(bs + (wid * 32 + 16) * DK), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ls[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPL + tn * 32 + (lane & 31)] = acc[tm][tn][r];
-        __syncthreads();
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment reads: lane (r = lane & 31, h = lane >> 5) takes k-piece q = 2j + h of rows r and r + 32
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 2) & 3;  // ((r + 32) >> 2) & 3 is the same
+    const int a_base = (wm * 64 + fr) * DK, b_base = (wn * 64 + fr) * DK;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
+        const float* As = smem + buf * (2 * BM * DK);
+        const float* Bs = As + BM * DK;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int lrow = (lane >> 4) + 4 * i;
-            const int64_t row = m0 + wm * 64 + tm * 32 + lrow;
-            const bool ok = col_ok && row < g.M;
-            f32x4 v = *reinterpret_cast<const f32x4*>(Ls + lrow * EPL + col4);
-            v += bias4;
-            if (ok) {
-                if (flags & PN_EPI_ROWBIAS) {
-                    int64_t ray = row / g.rows_per_ray;
-                    if (g.rb_mod > 0) ray %= g.rb_mod;
-                    v += *reinterpret_cast<const f32x4*>(g.rowbias + ray * g.ldrb + gcol);
-                }
-                if (flags & PN_EPI_ADDC) v += *reinterpret_cast<const f32x4*>(g.addc + row * g.ldadd + gcol);
-            }
-            if (flags & PN_EPI_RELU) {
-                v[0] = fmaxf(v[0], 0.f);
-                v[1] = fmaxf(v[1], 0.f);
-                v[2] = fmaxf(v[2], 0.f);
-                v[3] = fmaxf(v[3], 0.f);
-            }
-            if ((flags & PN_EPI_GATE) && ok) {
-                f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + row * g.ldg + gcol);
+        for (int j = 0; j < DK / 8; ++j) {
+            const int qo = (((2 * j + fh) ^ sw) & 3) * 4;
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(As + a_base + qo);
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(As + a_base + 32 * DK + qo);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + b_base + qo);
+            f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + b_base + 32 * DK + qo);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = gt[c] > 0.f ? v[c] : 0.f;
-            }
-            if ((flags & PN_EPI_GATEBITS) && ok) {
-                uint32_t w = g.gate_bits[row * PN_MASK_WORDS + (gcol >> 5)];
-                const int bi = (gcol >> 2) & 7;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = ((w >> (c * 8 + bi)) & 1u) ? v[c] : 0.f;
-            }
-            if (flags & PN_EPI_MASKOUT) {  // all 64 lanes take part in the ballots
-                uint32_t word = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    unsigned long long b = __ballot(v[c] > 0.f);
-                    word |= (uint32_t)((b >> ((lane >> 3) * 8)) & 0xffull) << (c * 8);
-                }
-                if (ok && (lane & 7) == 0) g.mask_out[row * PN_MASK_WORDS + (gcol >> 5)] = word;
-            }
-            if (ok) {
-                if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + gcol) = v;
-                csum += v;
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next chunk has landed
         __syncthreads();
     }
-    if (flags & PN_EPI_COLSUM) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float x = csum[c];
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
-            csum[c] = x;
-        }
-        if (lane < 16 && col_ok) {
-            const int64_t prow = (m0 / 64) + wm;
-            *reinterpret_cast<f32x4*>(g.colsum + prow * g.N + gcol) = csum;
-        }
-    }
+    nt_epilogue(g, acc, smem, m0, n0, lane, wid, wm, wn);
 }
 
 int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
@@ -371,7 +469,10 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     double tile_cycles = 3.0 * 64.0 * 64.0 * ((ksum + BK - 1) / BK);
     gg.stagger = (nwg > 768 && !(g_dbg & 8)) ? (int)(tile_cycles / 3.0 / 8128.0 + 0.5) : 0;
     if (g_dbg & 16) gg.stagger *= 2;
-    hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
+    bool dma = !(g_dbg & 64) && !(g.flags & 0x200);
+    for (int i = 0; i < g.nseg; ++i) dma = dma && (g.seg[i].K % DK == 0);
+    if (dma) hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
+    else hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
@@ -528,8 +629,6 @@ __global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2, int nti
 // global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KiB contiguously into LDS, so the [32][128] chunk image
 // is filled row-pair by row-pair with no staging registers and no ds_write; two LDS buffers keep the next
 // chunk's DMA in flight under the current chunk's MFMAs with ONE barrier per chunk.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 __global__ __launch_bounds__(256) void k_gemm_tn_dma(PnTnArgs g, int tiles2, int ntiles, int nsplit) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * BM];  // [buf][X|Y][32][128] = 64 KB
