@@ -107,18 +107,27 @@ __global__ __launch_bounds__(256) void k_head_fwd(int64_t M, const float* x, int
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) w[c][v] = W[c * (64 * VEC) + lane * VEC + v];
-    for (int64_t row = wave; row < M; row += nwaves) {
-        float xv[VEC];
+    // 4 rows per iteration: four independent 1-KB row loads in flight per wave (the kernel is HBM-latency bound)
+    for (int64_t row0 = wave * 4; row0 < M; row0 += nwaves * 4) {
+        float xv[4][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) xv[v] = x[row * ldx + lane * VEC + v];
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = row0 + u < M ? row0 + u : M - 1;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float s = 0.f;
+            for (int v = 0; v < VEC; ++v) xv[u][v] = x[row * ldx + lane * VEC + v];
+        }
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) s += xv[v] * w[c][v];
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = row0 + u;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) out[row * ldo + c] = s + (b ? b[c] : 0.f);
+            for (int c = 0; c < NC; ++c) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s += xv[u][v] * w[c][v];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (lane == 0 && row < M) out[row * ldo + c] = s + (b ? b[c] : 0.f);
+            }
         }
     }
 }
@@ -135,17 +144,29 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(int64_t M, const float* d
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) w[c][v] = W[c * (64 * VEC) + lane * VEC + v];
-    for (int64_t row = wave; row < M; row += nwaves) {
-        float dv[NC];
+    for (int64_t row0 = wave * 4; row0 < M; row0 += nwaves * 4) {
+        float dv[4][NC];
+        float gt[4][VEC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) dv[c] = d[row * ldd + c];
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = row0 + u < M ? row0 + u : M - 1;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            float s = 0.f;
+            for (int c = 0; c < NC; ++c) dv[u][c] = d[row * ldd + c];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) s += dv[c] * w[c][v];
-            if (gate && !(gate[row * ldg + lane * VEC + v] > 0.f)) s = 0.f;
-            out[row * ldo + lane * VEC + v] = s;
+            for (int v = 0; v < VEC; ++v) gt[u][v] = gate ? gate[row * ldg + lane * VEC + v] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = row0 + u;
+            if (row >= M) break;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) s += dv[u][c] * w[c][v];
+                if (!(gt[u][v] > 0.f)) s = 0.f;
+                out[row * ldo + lane * VEC + v] = s;
+            }
         }
     }
 }
@@ -243,14 +264,19 @@ __device__ __forceinline__ float sp_d2(float x) {
 }
 
 // seed of the density-gradient sweep: r7[row][j] = softplus'(z_row) * Wd[0][j] * [h7[row][j] > 0]
-__global__ void k_dgrad_seed(int64_t M, int nc, float bias, const float* raw_density, const float* Wd, const float* h7,
-                             float* r7) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * PN_WIDTH) return;
-    int64_t row = idx >> 8;
-    int j = (int)(idx & 255);
+__global__ void k_dgrad_seed(int64_t M, int nc, float bias, const float* raw_density, const float* Wd,
+                             const uint32_t* mask7, float* r7) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per float4 of the output
+    if (idx >= M * (PN_WIDTH / 4)) return;
+    int64_t row = idx >> 6;
+    int j = (int)(idx & 63) * 4;
     float s = sp_d1(raw_density[row * nc] + bias);
-    r7[idx] = (h7[idx] > 0.f) ? s * Wd[j] : 0.f;
+    uint32_t wbits = mask7[row * PN_MASK_WORDS + (j >> 5)];
+    const int bi = (j >> 2) & 7;
+    f32x4 wv = *reinterpret_cast<const f32x4*>(Wd + j), o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = ((wbits >> (c * 8 + bi)) & 1u) ? s * wv[c] : 0.f;
+    *reinterpret_cast<f32x4*>(r7 + row * PN_WIDTH + j) = o;
 }
 
 // second-order seed: dden[row][0] += softplus''(z) * sdot[row];   coef[row] = softplus'(z)
@@ -448,8 +474,8 @@ int pn_density_grad(int64_t M, int nc, float density_bias, const float* params, 
     const int64_t Mp = pn_pad(M);
     auto act = [&](int i) { return acts + (int64_t)i * Mp * PN_WIDTH; };
     auto rs = [&](int i) { return rsweep + (int64_t)i * Mp * PN_WIDTH; };
-    hipLaunchKernelGGL(k_dgrad_seed, dim3(nblk(M * PN_WIDTH, 256)), dim3(256), 0, s, M, nc, density_bias, raw_density,
-                       params + L.wd, act(7), rs(7));
+    hipLaunchKernelGGL(k_dgrad_seed, dim3(nblk(M * (PN_WIDTH / 4), 256)), dim3(256), 0, s, M, nc, density_bias,
+                       raw_density, params + L.wd, masks + (int64_t)7 * Mp * PN_MASK_WORDS, rs(7));
     PN_CHECK_LAUNCH();
     for (int l = 7; l >= 1; --l) {  // r_{l-1} = [h_{l-1} > 0] * (r_l * W_l[:, :256])
         PnGemmNt g = nt(M, PN_WIDTH, rs(l), PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, rs(l - 1), PN_WIDTH);
