@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--cpu-rays", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,36 +131,87 @@ def main():
         dist.broadcast(model.mlp.flat_params(), 0)
     opt = pn.FlatAdam(model.mlp, lr=2e-4)
     lo, hi = shard_bounds(args.global_batch, rank, world)
-    idx_gen = torch.Generator(device=dev)
-    idx_gen.manual_seed(4)  # same index stream on every rank; each takes its own slice
-    torch.manual_seed(1234 + rank)  # jitter noise differs per rank, like per-process DDP workers
+    nb = hi - lo
+    torch.manual_seed(1234 + rank)  # every rank draws ITS slice of the global batch and its own jitter noise
+    lr_dev = torch.zeros(1, device=dev)
 
-    def step(i):
-        idx = torch.randint(0, n_pool, (args.global_batch,), generator=idx_gen, device=dev)[lo:hi]
+    def fwd_bwd():
+        """Sample this rank's rays from the HBM pool, render, loss, backward -> (loss, flat gradient)."""
+        idx = torch.randint(0, n_pool, (nb,), device=dev)
         rays = pn.Rays(*[x[idx] for x in pool])
         gt = gt_pool[idx]
         opt.zero_grad()
         outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
         loss, _ = pn.pano_loss(outs, rays.lossmult, gt)
         loss.backward()
-        g = model.mlp.last_flat_grad
+        return loss.detach(), outs[1][0].detach(), gt, model.mlp.last_flat_grad
+
+    graph = None
+    state = {}
+
+    def step(i):
+        lr_dev.fill_(pn.mip_lr(i))
+        if graph is not None:
+            graph.replay()
+            loss, pred, gt, g = state["out"]
+            if world == 1:
+                return loss, pred, gt  # Adam is part of the graph
+        else:
+            loss, pred, gt, g = fwd_bwd()
         if world > 1:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        opt.step(flat_grad=g, grad_scale=1.0 / world, lr=pn.mip_lr(i))
-        return loss, outs, gt
+        opt.step_dev(g, lr_dev, grad_scale=1.0 / world)
+        return loss, pred, gt
+
+    def try_capture():
+        """Whole-step capture: ~700 launches become one graph launch (the step is launch-latency sensitive at
+        512 rays per GPU).  Falls back to eager launches if capture is not possible."""
+        nonlocal graph
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                out = fwd_bwd()
+                opt.step_dev(out[3], lr_dev, grad_scale=1.0 / world) if world == 1 else None
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        from pano_nerf_amd.mlp import mark_dirty
+        mark_dirty(model.mlp)  # the weight re-pack must be part of the captured sequence (weights change every step)
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            out = fwd_bwd()
+            if world == 1:
+                opt.step_dev(out[3], lr_dev, grad_scale=1.0)
+        state["out"] = out
+        graph = g_
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # graph replay pays when the step is launch-latency sensitive (<= 1024 rays per GPU: +5 %); at 4096 rays per GPU
+    # the 700-node replay is ~1.5 % slower than eager launches, so `auto` keeps those eager
+    use_graph = args.graph == "on" or (args.graph == "auto" and nb <= 1024)
+    if use_graph:
+        try:
+            try_capture()
+        except Exception as e:  # keep going with eager launches
+            if args.graph == "on":
+                raise
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     fence()
     _lib.load().pn_prof_enable(1)
     t0 = time.perf_counter()
+    prof_live = graph is None  # HIP events cannot be recorded inside a replayed graph: the roofline leg below runs eagerly
+    if not prof_live:
+        _lib.load().pn_prof_enable(0)
     for i in range(args.steps):
-        loss, outs, gt = step(args.warmup + i)
+        loss, pred, gt = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
     prof = {}
@@ -167,6 +220,18 @@ def main():
         _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
         prof[name] = (ms.value, n.value, fl.value)
     _lib.load().pn_prof_enable(0)
+    if not prof_live:  # graph mode: measure the per-launch figures on 2 eager steps right after the timed region
+        eager_graph, graph = graph, None
+        _lib.load().pn_prof_enable(1)
+        for i in range(2):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        for cls, name in ((0, "k_gemm_nt"), (1, "k_gemm_tn")):
+            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+            prof[name] = (ms.value, n.value, fl.value)
+        _lib.load().pn_prof_enable(0)
+        graph = None
     # the same kernels with the side stream off: per-launch durations without time-sharing (not part of `value`)
     iso = {}
     if rank == 0:
@@ -190,7 +255,7 @@ def main():
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = args.global_batch * args.steps / elapsed
-    psnr = pn.loss.hdr_to_ldr_psnr(outs[1][0].detach(), gt)
+    psnr = pn.loss.hdr_to_ldr_psnr(pred, gt)
 
     if rank == 0:
         dom = max(prof, key=lambda k: prof[k][0])
@@ -213,10 +278,14 @@ def main():
                                    f"surface+chrom+ort loss, Adam; global batch {args.global_batch} rays "
                                    f"({hi - lo} per GPU)",
                        "global_batch": args.global_batch, "rays_per_gpu": hi - lo, "num_samples": args.samples,
-                       "parallelism": f"dp{world} (rays sharded, one 2.455 MB gradient all-reduce/step)"},
+                       "parallelism": f"dp{world} (rays sharded, one 2.455 MB gradient all-reduce/step)",
+                       "launch": "hip-graph replay" if not prof_live else "eager"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "avg_launch_us": avg_us, "launches": n,
+                         "measured": "HIP events around every GEMM launch " + ("during the timed region" if prof_live else
+                                     "on 2 eager steps right after the timed region (events cannot be recorded inside a "
+                                     "replayed graph; same kernels, same shapes)"),
                          "note": "timed region runs the weight-gradient GEMMs (k_gemm_tn) on a side stream, concurrently "
                                  "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the same "
                                  "kernels in 2 extra steps with the side stream off",

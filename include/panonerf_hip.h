@@ -203,6 +203,12 @@ int pn_tonemap_loss(int64_t B, const float* rgb_gt_hdr, const float* lossmult, c
 int pn_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float lr,
                  float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* same update with the step counter (incremented first) and the learning rate read from device memory, so the
+ * call can be captured once in a HIP graph and replayed every step */
+int pn_adam_step_dev(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                     const float* lr_dev, float beta1, float beta2, float eps, int* step_dev, float grad_scale,
+                     void* stream);
+
 /* ---- building blocks exposed for tests / profiling ------------------------------------
  * C[M,N] = epi(A[M,K] * Bt[N,K]^T) on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * flags: 1 = +bias[N], 2 = relu, 4 = gate by (gate[row,col] > 0). lda/ldb/ldc/ldg in floats. */

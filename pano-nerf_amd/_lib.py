@@ -41,6 +41,7 @@ SIGNATURES = {
     "pn_env_origin_backward": ("i", "lipppp"),
     "pn_tonemap_loss": ("i", "l" + "p" * 6 + "fff" + "p" * 6 + "p"),
     "pn_adam_step": ("i", "lppppffffifp"),
+    "pn_adam_step_dev": ("i", "lpppppfffpfp"),
     "pn_gemm_nt": ("i", "liipipipippiip"),
     "pn_gemm_tn_work_floats": ("l", "lii"),
     "pn_gemm_tn": ("i", "liipipipiipp"),

@@ -746,6 +746,131 @@ __global__ __launch_bounds__(256) void k_gemm_tn_dma(PnTnArgs g, int tiles2, int
         }
 }
 
+// ---- TN, 128 x 256 output tile (weight gradients of the 256 x 256 layers) ---------------------------------
+// 4 waves, each a 128 x 64 slab = 4 x 2 MFMA tiles (128 accumulator registers): per k-step ONE ds_read_b128 of X
+// (columns 4i..4i+3 -> tile tm covers the stride-4 set {4i + tm}) and ONE ds_read_b64 of Y feed 8 MFMAs, half the
+// LDS instructions per MFMA of the 128 x 128 kernel.  16-row sub-chunks by LDS-DMA, two buffers (48 KB).
+#define TW 16
+__global__ __launch_bounds__(256, 3) void k_gemm_tn_wide(PnTnArgs g, int tiles2, int ntiles, int nsplit) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * TW * (128 + 256)];  // 48 KB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
+    const int tile = jj % ntiles;
+    const int64_t split = (int64_t)(jj / ntiles) * 8 + xcd;
+    if (split >= nsplit) return;
+    const int i0 = (tile / tiles2) * 128, j0 = (tile % tiles2) * 256;
+    const int64_t c_begin = split * (g.rows_per_split / BK);
+    int64_t c_end = c_begin + g.rows_per_split / BK;
+    if (c_end > g.chunks_total) c_end = g.chunks_total;
+
+    const float* const X0 = g.seg[0].X;
+    const float* const Y0 = g.seg[0].Y;
+    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
+    const int64_t M0 = g.seg[0].M;
+    const float* const X1 = g.seg[1].X;
+    const float* const Y1 = g.seg[1].Y;
+    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
+    const int64_t M1 = g.seg[1].M;
+    const int64_t chunks0 = g.chunks0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto seg_of = [&](int64_t sc, const float*& X, const float*& Y, int& ldx, int& ldy, int64_t& Mseg, int64_t& r0) {
+        const int64_t c = sc >> 1;
+        const bool s1 = c >= chunks0;
+        X = s1 ? X1 : X0;
+        Y = s1 ? Y1 : Y0;
+        ldx = s1 ? ldx1 : ldx0;
+        ldy = s1 ? ldy1 : ldy0;
+        Mseg = s1 ? M1 : M0;
+        r0 = (s1 ? c - chunks0 : c) * BK + (sc & 1) * TW;
+    };
+    // X sub-chunk [16][128]: 8 pieces of 2 rows; Y sub-chunk [16][256]: 16 pieces of 1 row.  Wave w: X pieces 2w, 2w+1
+    // and Y pieces 4w .. 4w+3.
+    auto stage = [&](int64_t sc, int buf) {
+        const float *X, *Y;
+        int ldx, ldy;
+        int64_t Mseg, r0;
+        seg_of(sc, X, Y, ldx, ldy, Mseg, r0);
+        float* xs = smem + buf * (TW * 384);
+        float* ys = xs + TW * 128;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int piece = wid * 2 + p;
+            int64_t gr = r0 + piece * 2 + (lane >> 5);
+            gr = gr < Mseg ? gr : Mseg - 1;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(X + gr * ldx + i0 + (lane & 31) * 4), (lds_ptr_t)(xs + piece * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = wid * 4 + p;  // = row
+            int64_t gr = r0 + piece;
+            gr = gr < Mseg ? gr : Mseg - 1;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Y + gr * ldy + j0 + lane * 4), (lds_ptr_t)(ys + piece * 256), 16, 0, 0);
+        }
+    };
+    auto valid_rows = [&](int64_t sc) -> int {
+        const float *X, *Y;
+        int ldx, ldy;
+        int64_t Mseg, r0;
+        seg_of(sc, X, Y, ldx, ldy, Mseg, r0);
+        const int64_t v = Mseg - r0;
+        return v >= TW ? TW : (v < 0 ? 0 : (int)v);
+    };
+
+    const int64_t s_begin = 2 * c_begin, s_end = 2 * c_end;
+    if (s_begin < s_end) {
+        stage(s_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int xo = (lane >> 5) * 128 + 4 * (lane & 31);
+        const int yo = (lane >> 5) * 256 + wid * 64 + 2 * (lane & 31);
+        for (int64_t sc = s_begin; sc < s_end; ++sc) {
+            const int buf = (int)((sc - s_begin) & 1);
+            float* Xs = smem + buf * (TW * 384);
+            float* Ys = Xs + TW * 128;
+            const int vr = valid_rows(sc);
+            if (vr < TW) {  // ragged tail of a segment: zero the rows past the end (uniform branch)
+                for (int e = tid; e < (TW - vr) * 128; e += 256) Xs[vr * 128 + e] = 0.f;
+                for (int e = tid; e < (TW - vr) * 256; e += 256) Ys[vr * 256 + e] = 0.f;
+                __syncthreads();
+            }
+            if (sc + 1 < s_end) stage(sc + 1, buf ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < TW / 2; ++kk) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(Xs + xo + kk * 2 * 128);
+                f32x2 b = *reinterpret_cast<const f32x2*>(Ys + yo + kk * 2 * 256);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[0], acc[tm][0], 0, 0, 0);
+                    acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[1], acc[tm][1], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    float* out = g.slab + split * (int64_t)g.N1 * g.N2;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = j0 + wid * 64 + 2 * (lane & 31) + tn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + tm;
+                out[(int64_t)row * g.N2 + col] = acc[tm][tn][r];
+            }
+        }
+}
+
 // Deterministic sum over a leading "partials" dimension: out[e] = sum_b src[b*stride + e'] for the
 // elements e of a [rows, cols] block.  One block = 64 elements x 4 partial lanes; grid.y splits the partials.
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols,
@@ -764,7 +889,20 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* src, int64_t n
         r = e / cols;
         c = e % cols;
         const float* p = src + (int64_t)r * src_ld + c;
-        for (int64_t b = b0 + ty; b < b1; b += 4) acc += p[b * stride];
+        int64_t b = b0 + ty;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+        for (; b + 28 < b1; b += 32) {  // eight independent loads in flight per thread
+            a0 += p[b * stride];
+            a1 += p[(b + 4) * stride];
+            a2 += p[(b + 8) * stride];
+            a3 += p[(b + 12) * stride];
+            a4 += p[(b + 16) * stride];
+            a5 += p[(b + 20) * stride];
+            a6 += p[(b + 24) * stride];
+            a7 += p[(b + 28) * stride];
+        }
+        for (; b < b1; b += 4) a0 += p[b * stride];
+        acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     }
     red[ty][tx] = acc;
     __syncthreads();
@@ -798,6 +936,10 @@ static int tn_splits(int64_t Mtotal, int N1, int N2) {
     int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
     int64_t chunks = (Mtotal + BK - 1) / BK + 1;
     int64_t want = (1024 + tiles - 1) / tiles;   // ~4 workgroups per CU
+    if ((N1 % 128 == 0) && (N2 % 256 == 0)) {    // wide-tile kernel: 3 workgroups per CU
+        tiles = (N1 / 128) * (N2 / 256);
+        want = 768 / tiles;
+    }
     int64_t per = (chunks + want - 1) / want;    // chunks per split
     if (per < 4) per = 4;
     return (int)((chunks + per - 1) / per);
@@ -826,6 +968,7 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
     g.N2 = N2;
     g.chunks0 = (segs[0].M + BK - 1) / BK;
     g.chunks_total = g.chunks0 + (nseg > 1 ? (segs[1].M + BK - 1) / BK : 0);
+    const bool wide = (N1 % 128 == 0) && (N2 % 256 == 0) && !(g_dbg & 128);
     int nsplit = tn_splits(Mtotal, N1, N2);
     int64_t per = (g.chunks_total + nsplit - 1) / nsplit;
     g.rows_per_split = per * BK;
@@ -836,7 +979,10 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
         const int ntiles = tiles1 * tiles2;
         const int groups = (nsplit + 7) / 8;
         const bool full = (N1 % BM == 0) && (N2 % BN == 0) && !(g_dbg & 32);
-        if (full) hipLaunchKernelGGL(k_gemm_tn_dma, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
+        if (wide) {
+            const int t2 = N2 / 256, nt2 = (N1 / 128) * t2;
+            hipLaunchKernelGGL(k_gemm_tn_wide, dim3(groups * nt2 * 8), dim3(256), 0, s, g, t2, nt2, nsplit);
+        } else if (full) hipLaunchKernelGGL(k_gemm_tn_dma, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
         else hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
     }
     PN_CHECK_LAUNCH();

@@ -944,6 +944,23 @@ __global__ void k_adam(int64_t n, float* p, const float* g, float* m, float* v, 
     p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// graph-replay friendly form: the step counter and the learning rate live in device memory
+__global__ void k_adam_tick(int* step) { *step += 1; }
+__global__ void k_adam_dev(int64_t n, float* p, const float* g, float* m, float* v, const float* lr_dev, float b1,
+                           float b2, float eps, const int* step_dev, float gscale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = (float)(*step_dev);
+    const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    float gi = g[i] * gscale;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (*lr_dev / bc1) * (mi / denom);
+}
+
 // ============================================================================ C entry points
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 #define ST(s) ((hipStream_t)(s))
@@ -1166,6 +1183,19 @@ int pn_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, f
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(k_adam, dim3(nblk(n, 256)), dim3(256), 0, ST(stream), n, params, grads, exp_avg, exp_avg_sq, lr,
                        beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+int pn_adam_step_dev(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                     const float* lr_dev, float beta1, float beta2, float eps, int* step_dev, float grad_scale,
+                     void* stream) {
+    if (n <= 0) return PN_ERR_BAD_SHAPE;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return PN_ERR_NULL;
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, ST(stream), step_dev);
+    PN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_adam_dev, dim3(nblk(n, 256)), dim3(256), 0, ST(stream), n, params, grads, exp_avg, exp_avg_sq,
+                       lr_dev, beta1, beta2, eps, step_dev, grad_scale);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }

@@ -42,6 +42,22 @@ class FlatAdam:
                       torch.cuda.current_stream(flat.device).cuda_stream)
         mark_dirty(self.mlp)
 
+    def step_dev(self, flat_grad, lr_dev, grad_scale=1.0):
+        """Graph-replay friendly step: learning rate read from the 1-element device tensor `lr_dev`, step counter
+        kept (and incremented) on the device."""
+        flat = self.mlp.flat_params()
+        if not hasattr(self, "step_dev_t") or self.step_dev_t.device != flat.device:
+            self.step_dev_t = torch.full((1,), self.step_count, dtype=torch.int32, device=flat.device)
+        if self.exp_avg.device != flat.device:
+            self.exp_avg, self.exp_avg_sq = self.exp_avg.to(flat.device), self.exp_avg_sq.to(flat.device)
+        self.step_count += 1
+        with torch.cuda.device(flat.device):
+            _lib.call("pn_adam_step_dev", flat.numel(), flat.data_ptr(), flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                      self.exp_avg_sq.data_ptr(), lr_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]),
+                      float(self.eps), self.step_dev_t.data_ptr(), float(grad_scale),
+                      torch.cuda.current_stream(flat.device).cuda_stream)
+        mark_dirty(self.mlp)
+
     def zero_grad(self):
         for p in self.mlp.parameters():
             p.grad = None
