@@ -1,0 +1,75 @@
+"""Edge cases through the drop-in modules and the C ABI: ragged / tiny / maximum sizes, refused arguments."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import pano_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def scene_rays(B, stride=5):
+    flat, rgbs, radius, _ = orc.synthetic_scene(8, 16, 3, seed=4)
+    idx = (torch.arange(B) * stride) % flat.origins.shape[0]
+    return orc.Rays(*[x[idx] for x in flat]), rgbs[idx], radius
+
+
+@pytest.mark.parametrize("B,N", [(1, 8), (3, 2), (130, 16), (257, 33)])
+def test_ragged_and_tiny_batches_match_oracle(B, N):
+    """B not a multiple of the 128-row GEMM tile, a single ray, the smallest sample count (N = 2), odd N."""
+    import pano_nerf_amd as pn
+    rays_c, rgbs, radius = scene_rays(B)
+    rays = pn.Rays(*[x.to(dev()) for x in rays_c])
+    env = pn.generate_lit_rays(10, radius)
+    params = orc.init_params(4, 5)
+    model = pn.PanoMipNeRF(num_samples=N, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5)
+    model.mlp.load_state_dict(params)
+    model = model.to(dev())
+    outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    loss, _ = pn.pano_loss(outs, rays.lossmult, rgbs.to(dev()))
+    loss.backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = orc.pano_forward(p, rays_c, orc.Rays(*[x.cpu() for x in env]), num_samples=N)
+    ref_loss = orc.pano_loss(ref, rays_c.lossmult, rgbs)
+    for lvl in (0, 1):
+        assert rel_err(outs[lvl][0].detach().cpu(), ref[lvl][0].detach()) < 1e-4
+        assert rel_err(outs[lvl][1].detach().cpu(), ref[lvl][1].detach()) < 1e-4
+    assert rel_err(outs[1][4].detach().cpu(), ref[1][4].detach()) < 1e-4  # albedo
+    assert abs(float(loss) - float(ref_loss)) < 2e-3 * abs(float(ref_loss))
+    g = model.mlp.last_flat_grad
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    ref_g = torch.autograd.grad(ref_loss, list(p.values()))
+    ref_norm = float(torch.cat([x.reshape(-1) for x in ref_g]).norm())
+    assert abs(float(g.norm()) - ref_norm) < 5e-2 * ref_norm
+
+
+def test_maximum_sample_count():
+    """N = 512 is the most one wavefront scans (PN_MAX_SAMPLES); weights stay a sub-probability and sorted t."""
+    import pano_nerf_amd as pn
+    rays_c, _, _ = scene_rays(4)
+    rays = pn.Rays(*[x.to(dev()) for x in rays_c])
+    model = pn.MipNeRF(num_samples=512, rgb_activation="softplus", mlp_num_density_channels=1).to(dev())
+    with torch.no_grad():
+        outs = model(rays=rays, randomized=True, white_bkgd=True, use_ort_loss=False)
+    assert torch.isfinite(outs[1][0]).all() and bool((outs[1][1] >= 0).all()) and bool((outs[1][1] <= 10).all())
+    with pytest.raises(NotImplementedError):
+        pn.MipNeRF(num_samples=513, rgb_activation="softplus")
+
+
+def test_refused_arguments():
+    from pano_nerf_amd import _lib
+    h = _lib.load()
+    x = torch.zeros(64, device=dev())
+    p = x.data_ptr()
+    assert h.pn_sample_coarse(0, 8, p, p, p, p, p, None, p, p, p, None) == -1          # empty batch
+    assert h.pn_sample_coarse(4, 513, p, p, p, p, p, None, p, p, p, None) == -2        # beyond PN_MAX_SAMPLES
+    assert h.pn_sample_coarse(4, 8, None, p, p, p, p, None, p, p, p, None) == -3       # null pointer
+    assert h.pn_composite_forward(4, 8, 3, -1.0, 0.0, 0, p, p, p, p, 4, p, p, p, p, None) == -2  # density channels
+    assert h.pn_resample(4, 1, p, p, 0.01, None, p, p, p, p, p, p, None) == -1
+    with pytest.raises(RuntimeError, match="bad shape"):
+        _lib.call("pn_ipe_encode", 0, p, p, p, None)
