@@ -119,11 +119,12 @@ def main():
         m = torch.eye(4)
         m[:3, 3] = torch.rand(3, generator=gcpu) - 0.5
         cams.append(m.numpy())
-    pools = [pn.generate_pano_rays(args.height, args.width, c, 0.0, 10.0, device=dev) for c in cams]
-    pool = pn.Rays(*[torch.cat([getattr(p, k) for p in pools], 0) for k in pn.Rays_keys])
+    ray_pool = pn.DeviceRayPool(args.height, args.width, cams, near=0.0, far=10.0, device=dev)
+    pool = ray_pool.rays
     gt_pool = analytic_radiance(pool.viewdirs, pool.origins)
-    env = pn.generate_lit_rays(10, pn.rays.pano_pixel_radius(pools[0]), device=dev)
-    n_pool = pool.origins.shape[0]
+    ray_pool.rgbs = gt_pool
+    env = ray_pool.lit_rays(10)
+    n_pool = len(ray_pool)
 
     model = pn.PanoMipNeRF(num_samples=args.samples, rgb_activation="softplus", rgb_padding=0,
                            mlp_num_density_channels=5, num_env_samples=10).to(dev)
@@ -137,9 +138,7 @@ def main():
 
     def fwd_bwd():
         """Sample this rank's rays from the HBM pool, render, loss, backward -> (loss, flat gradient)."""
-        idx = torch.randint(0, n_pool, (nb,), device=dev)
-        rays = pn.Rays(*[x[idx] for x in pool])
-        gt = gt_pool[idx]
+        rays, gt = ray_pool.sample(nb)
         opt.zero_grad()
         outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
         loss, _ = pn.pano_loss(outs, rays.lossmult, gt)
@@ -178,7 +177,8 @@ def main():
         from pano_nerf_amd.mlp import mark_dirty
         mark_dirty(model.mlp)  # the weight re-pack must be part of the captured sequence (weights change every step)
         g_ = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_):
+        # thread_local: RCCL's helper threads may touch HIP while we capture; they must not invalidate the capture
+        with torch.cuda.graph(g_, capture_error_mode="thread_local" if world > 1 else "global"):
             out = fwd_bwd()
             if world == 1:
                 opt.step_dev(out[3], lr_dev, grad_scale=1.0)

@@ -10,7 +10,8 @@ Public surface (mirrors the reference's names):
 """
 __version__ = "0.1.0"
 
-from .rays import Rays, Rays_keys, namedtuple_map, rearrange_render_image, generate_pano_rays, generate_lit_rays  # noqa
+from .rays import (Rays, Rays_keys, namedtuple_map, rearrange_render_image, generate_pano_rays, generate_lit_rays,  # noqa
+                   DeviceRayPool)
 from .render import PanoMipNeRF, MipNeRF  # noqa
 from .loss import pano_loss, mip_loss  # noqa
 from .optim import FlatAdam, mip_lr  # noqa

@@ -62,3 +62,37 @@ def rearrange_render_image(rays, chunk_size=4096):
     n = flat[0].shape[0]
     chunks = [Rays(*[a[i:i + chunk_size] for a in flat]) for i in range(0, n, chunk_size)]
     return chunks, val_mask
+
+
+class DeviceRayPool:
+    """HBM-resident ray pool + batch sampler.
+
+    Stands in for the reference's flattened numpy pool and its 28 DataLoader workers
+    (datasets/pano_datasets.py:133-150, 271-275; systems/base_system.py:89-96): rays are generated on the device
+    from the camera matrices by ``pn_raygen_pano`` (nothing crosses PCIe per step) and a training batch is one
+    ``torch.randint`` + gather on the device.  ``images`` (optional) are the [H, W, 3] HDR targets per camera.
+    """
+
+    def __init__(self, height, width, c2ws, images=None, near=0.0, far=10.0, device="cuda"):
+        self.h, self.w = int(height), int(width)
+        pools = [generate_pano_rays(height, width, c, near, far, device=device) for c in c2ws]
+        self.rays = Rays(*[torch.cat([getattr(p, k) for p in pools], 0) for k in Rays_keys])
+        self.radius = pano_pixel_radius(pools[0])
+        self.rgbs = None
+        if images is not None:
+            self.rgbs = torch.cat([torch.as_tensor(im, dtype=torch.float32).reshape(-1, 3) for im in images], 0).to(
+                self.rays.origins.device)
+            if self.rgbs.shape[0] != len(self):
+                raise ValueError("images must be [H, W, 3] per camera")
+
+    def __len__(self):
+        return self.rays.origins.shape[0]
+
+    def sample(self, batch_size, generator=None):
+        """-> (Rays of [B, C], rgb [B, 3] or None), all on the device."""
+        idx = torch.randint(0, len(self), (int(batch_size),), device=self.rays.origins.device, generator=generator)
+        rays = Rays(*[x[idx] for x in self.rays])
+        return rays, (self.rgbs[idx] if self.rgbs is not None else None)
+
+    def lit_rays(self, num=10, near=0.0, far=10.0):
+        return generate_lit_rays(num, self.radius, near, far, device=self.rays.origins.device)

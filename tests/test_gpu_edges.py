@@ -73,3 +73,20 @@ def test_refused_arguments():
     assert h.pn_resample(4, 1, p, p, 0.01, None, p, p, p, p, p, p, None) == -1
     with pytest.raises(RuntimeError, match="bad shape"):
         _lib.call("pn_ipe_encode", 0, p, p, p, None)
+
+
+def test_device_ray_pool():
+    import pano_nerf_amd as pn
+    cams = [np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)]
+    cams[1][:3, 3] = [0.1, 0.2, -0.3]
+    imgs = [np.full((8, 16, 3), 0.25, np.float32), np.full((8, 16, 3), 0.75, np.float32)]
+    pool = pn.DeviceRayPool(8, 16, cams, images=imgs)
+    assert len(pool) == 2 * 8 * 16
+    rays, rgb = pool.sample(64)
+    assert rays.origins.shape == (64, 3) and rgb.shape == (64, 3) and rays.radii.shape == (64, 1)
+    # a ray's colour comes from the camera its origin belongs to
+    cam1 = (rays.origins[:, 0] > 0.05)
+    assert torch.allclose(rgb[cam1], torch.full_like(rgb[cam1], 0.75)) and torch.allclose(rgb[~cam1], torch.full_like(rgb[~cam1], 0.25))
+    env = pool.lit_rays(10)
+    assert env.directions.dtype == torch.float16 and env.directions.shape == (10, 3)
+    assert abs(float(env.lossmult[0, 0]) - 4 * np.pi / 10) < 2e-3
