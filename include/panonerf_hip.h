@@ -224,6 +224,10 @@ int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* 
  * While enabled every GEMM launch is bracketed by HIP events on its own stream.  pn_prof_read waits
  * for the recorded events and returns, for kernel class cls (0 = k_gemm_nt, 1 = k_gemm_tn), the summed
  * duration in ms, the launch count and the summed algorithmic FLOPs (2*M*N*K, unpadded). */
+/* GEMM arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp32-accurate 3-term bf16 split on
+ * v_mfma_f32_32x32x16_bf16 (six partial products per product, fp32 accumulate).  Default 0 unless the environment
+ * variable PN_GEMM_MODE=1 is set before the first GEMM. */
+int pn_set_gemm_mode(int mode);
 /* diagnostic: `blocks` workgroups x 4 waves each issue 4*iters back-to-back fp32 MFMAs (no memory traffic) */
 int pn_mfma_probe(float* out, int blocks, int iters, void* stream);
 int pn_prof_enable(int on);

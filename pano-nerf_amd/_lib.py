@@ -45,6 +45,7 @@ SIGNATURES = {
     "pn_gemm_nt": ("i", "liipipipippiip"),
     "pn_gemm_tn_work_floats": ("l", "lii"),
     "pn_gemm_tn": ("i", "liipipipiipp"),
+    "pn_set_gemm_mode": ("i", "i"),
     "pn_mfma_probe": ("i", "piip"),
     "pn_prof_enable": ("i", "i"),
     "pn_prof_read": ("i", "ippp"),

@@ -15,6 +15,7 @@
 // form each lane reads FOUR consecutive k of its row with one ds_read_b128 (lanes 0-31: k = 8j..8j+3,
 // lanes 32-63: k = 8j+4..8j+7) and feeds them to four consecutive MFMAs.
 #include "pn_common.h"
+#include <stdlib.h>
 #include <vector>
 
 // ---------------------------------------------------------------------------- launch timing
@@ -150,8 +151,9 @@ __device__ __forceinline__ void nt_store(float* As, float* Bs, int tid, const Nt
 
 // Shared epilogue of the NT kernels (see the comment inside).  `smem` is the (now idle) staging LDS, at least
 // 4 * 32 * EPL floats.
-__device__ __forceinline__ void nt_epilogue(const PnGemmNt& g, f32x16 (&acc)[2][2], float* smem, int64_t m0, int n0,
-                                            int lane, int wid, int wm, int wn) {
+template <int NT, int OFF>
+__device__ __forceinline__ void nt_epilogue_t(const PnGemmNt& g, f32x16 (&acc)[2][NT], float* smem, int64_t m0, int n0,
+                                              int lane, int wid, int wm, int wn) {
     // ---- epilogue.  The accumulators hold one column per lane (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), so a
     // direct store is 64 dword stores per lane, each touching two 128-B row segments.  Instead every wave
     // transposes its 32x64 half-tile through the (now free) staging LDS and streams full 256-B row segments
@@ -171,7 +173,7 @@ __device__ __forceinline__ void nt_epilogue(const PnGemmNt& g, f32x16 (&acc)[2][
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Ls[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPL + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+                Ls[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPL + tn * 32 + (lane & 31)] = acc[tm][OFF + tn][r];
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -234,6 +236,11 @@ __device__ __forceinline__ void nt_epilogue(const PnGemmNt& g, f32x16 (&acc)[2][
             *reinterpret_cast<f32x4*>(g.colsum + prow * g.N + gcol) = csum;
         }
     }
+}
+
+__device__ __forceinline__ void nt_epilogue(const PnGemmNt& g, f32x16 (&acc)[2][2], float* smem, int64_t m0, int n0,
+                                            int lane, int wid, int wm, int wn) {
+    nt_epilogue_t<2, 0>(g, acc, smem, m0, n0, lane, wid, wm, wn);
 }
 
 #ifndef PN_NT_OCC
@@ -439,6 +446,313 @@ __global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n,
     nt_epilogue(g, acc, smem, m0, n0, lane, wid, wm, wn);
 }
 
+// ---- NT on the bf16 matrix cores with fp32 accuracy: 3-term split ------------------------------------------
+// Every fp32 operand element x is split exactly as x = h + m + l with h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m) (3 x 8 = 24 mantissa bits).  The product a*b is accumulated in fp32 from the six partial
+// products of weight >= 2^-16 (hh, hm, mh, mm, hl, lh; the dropped ml, lm, ll are <= 2^-24 relative, the size of an
+// fp32 rounding), each a v_mfma_f32_32x32x16_bf16 — 16x the fp32-MFMA rate, so 6 of them cost 0.375 of one fp32
+// MFMA of the same tile.  Interfaces stay fp32: the split happens in the staging path (global fp32 -> registers ->
+// three bf16 planes in LDS); accumulators, epilogue and outputs are exactly those of the fp32 kernels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define SK 16  // K-chunk of the split kernels
+
+__device__ __forceinline__ void split4(const f32x4& x, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const __bf16 hh = (__bf16)x[c];
+        const float r1 = x[c] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[c] = hh;
+        m[c] = mm;
+        l[c] = (__bf16)r2;
+    }
+}
+
+// plane image: [3 planes][128 rows][16 k] bf16 (32-B rows); the two 16-B pieces of a row are swapped on rows with
+// bit 3 set, which makes both the 8-B staging writes and the 16-B fragment reads bank-conflict free
+__device__ __forceinline__ int s3_off(int plane, int row, int piece) {
+    return ((plane * 128 + row) * SK) + ((piece ^ ((row >> 3) & 1)) << 3);
+}
+
+struct S3Regs {
+    f32x4 a[2], b[2];
+};
+
+__global__ __launch_bounds__(256, 3) void k_gemm_nt_s3(PnGemmNt g, int tiles_n, int ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem_s[2 * 2 * 3 * 128 * SK];  // 2 buffers x (A,B) x 3 planes: 48 KB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nc0 = g.seg[0].K / SK;
+    const int nc1 = (g.nseg > 1) ? g.seg[1].K / SK : 0;
+    const int nchunks = nc0 + nc1;
+    const float* const A0 = g.seg[0].A;
+    const float* const B0 = g.seg[0].B;
+    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb;
+    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
+    const float* const B1 = g.nseg > 1 ? g.seg[1].B : B0;
+    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int64_t m0 = (int64_t)(t / tiles_n) * BM;
+    const int n0 = (t % tiles_n) * BN;
+
+    // staging: thread -> (row rr and rr + 64, k-quad q)
+    const int sq = tid & 3, srow = tid >> 2;
+    int64_t ar0 = m0 + srow, ar1 = ar0 + 64;
+    ar0 = ar0 < g.M ? ar0 : g.M - 1;
+    ar1 = ar1 < g.M ? ar1 : g.M - 1;
+    int br0 = n0 + srow, br1 = br0 + 64;
+    br0 = br0 < g.N ? br0 : g.N - 1;
+    br1 = br1 < g.N ? br1 : g.N - 1;
+    auto load = [&](int c, S3Regs& r) {
+        const bool s1 = c >= nc0;
+        const float* A = s1 ? A1 : A0;
+        const float* B = s1 ? B1 : B0;
+        const int lda = s1 ? lda1 : lda0, ldb = s1 ? ldb1 : ldb0;
+        const int k = (s1 ? c - nc0 : c) * SK + sq * 4;
+        r.a[0] = *reinterpret_cast<const f32x4*>(A + ar0 * lda + k);
+        r.a[1] = *reinterpret_cast<const f32x4*>(A + ar1 * lda + k);
+        r.b[0] = *reinterpret_cast<const f32x4*>(B + (int64_t)br0 * ldb + k);
+        r.b[1] = *reinterpret_cast<const f32x4*>(B + (int64_t)br1 * ldb + k);
+    };
+    auto store = [&](int buf, const S3Regs& r) {
+        unsigned short* as = smem_s + buf * (6 * 128 * SK);
+        unsigned short* bs = as + 3 * 128 * SK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + 64 * i;
+            const int o = ((sq >> 1) ^ ((row >> 3) & 1)) * 8 + (sq & 1) * 4;
+            bf16x4 h, m, l;
+            split4(r.a[i], h, m, l);
+            *reinterpret_cast<bf16x4*>(as + (0 * 128 + row) * SK + o) = h;
+            *reinterpret_cast<bf16x4*>(as + (1 * 128 + row) * SK + o) = m;
+            *reinterpret_cast<bf16x4*>(as + (2 * 128 + row) * SK + o) = l;
+            split4(r.b[i], h, m, l);
+            *reinterpret_cast<bf16x4*>(bs + (0 * 128 + row) * SK + o) = h;
+            *reinterpret_cast<bf16x4*>(bs + (1 * 128 + row) * SK + o) = m;
+            *reinterpret_cast<bf16x4*>(bs + (2 * 128 + row) * SK + o) = l;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    S3Regs regs;
+    load(0, regs);
+    store(0, regs);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load(c + 1, regs);
+        const unsigned short* as = smem_s + buf * (6 * 128 * SK);
+        const unsigned short* bs = as + 3 * 128 * SK;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[tt][p] = *reinterpret_cast<const bf16x8*>(as + s3_off(p, wm * 64 + tt * 32 + fr, fh));
+                b[tt][p] = *reinterpret_cast<const bf16x8*>(bs + s3_off(p, wn * 64 + tt * 32 + fr, fh));
+            }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                f32x16 v = acc[tm][tn];  // small terms first
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], v, 0, 0, 0);
+                acc[tm][tn] = v;
+            }
+        if (c + 1 < nchunks) store(buf ^ 1, regs);
+        __syncthreads();
+    }
+    nt_epilogue(g, acc, reinterpret_cast<float*>(smem_s), m0, n0, lane, wid, wm, wn);
+}
+
+// ---- wide split kernel: 128 x 256 output tile, pre-split weight planes by LDS-DMA ---------------------------
+// For the N = 256 layers.  4 waves as 2 x 2, each a 64 x 128 slab (2 x 4 MFMA tiles, 128 accumulator registers):
+// the A panel (activations) is split once per 256 output columns, the B operand (weights) arrives as bf16 planes
+// prepared once per optimizer step by pn_pack_weights and is moved global -> LDS by DMA with the swizzle on the
+// source address.  48 MFMAs per wave between barriers.
+struct PlaneRef {
+    const unsigned short* base;  // plane 0 of the element the fp32 pointer addresses; plane p at + p * stride
+    int64_t stride;
+};
+static const float* g_pl_f[2] = {nullptr, nullptr};       // fp32 blocks the planes mirror (params, wpack)
+static const unsigned short* g_pl_p[2] = {nullptr, nullptr};
+static int64_t g_pl_n[2] = {0, 0};
+void pn_register_planes(int which, const float* fbase, int64_t nfloats, const unsigned short* planes) {
+    g_pl_f[which] = fbase;
+    g_pl_n[which] = nfloats;
+    g_pl_p[which] = planes;
+}
+static bool lookup_planes(const float* B, PlaneRef& r) {
+    for (int i = 0; i < 2; ++i)
+        if (g_pl_f[i] && B >= g_pl_f[i] && B < g_pl_f[i] + g_pl_n[i]) {
+            r.base = g_pl_p[i] + (B - g_pl_f[i]);
+            r.stride = g_pl_n[i];
+            return true;
+        }
+    return false;
+}
+struct S3wArgs {
+    PlaneRef bp[2];
+};
+
+__device__ __forceinline__ int s3w_off(int plane, int rows, int row, int piece) {
+    return ((plane * rows + row) * SK) + ((piece ^ ((row >> 3) & 1)) << 3);
+}
+
+template <int WM>
+__global__ __launch_bounds__(128 * WM, 2) void k_gemm_nt_s3w(PnGemmNt g, S3wArgs w, int ntiles) {
+    constexpr int RM = 64 * WM;  // rows of the block tile
+    // per buffer: A planes 3 x [128][16] bf16 (12 KB) then B planes 3 x [256][16] bf16 (24 KB)
+    __shared__ __attribute__((aligned(16))) unsigned short smem_s[2 * (3 * RM * SK + 3 * 256 * SK)];  // 72 / 96 KB
+    constexpr int BUF = 3 * RM * SK + 3 * 256 * SK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nc0 = g.seg[0].K / SK;
+    const int nc1 = (g.nseg > 1) ? g.seg[1].K / SK : 0;
+    const int nchunks = nc0 + nc1;
+    const float* const A0 = g.seg[0].A;
+    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb;
+    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
+    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
+    const unsigned short* const P0 = w.bp[0].base;
+    const unsigned short* const P1 = g.nseg > 1 ? w.bp[1].base : P0;
+    const int64_t ps0 = w.bp[0].stride, ps1 = g.nseg > 1 ? w.bp[1].stride : ps0;
+    const int64_t m0 = (int64_t)blockIdx.x * RM;  // one tile column: N == 256
+
+    const int sq = tid & 3, srow = tid >> 2;
+    int64_t ar0 = m0 + srow, ar1 = ar0 + RM / 2;
+    ar0 = ar0 < g.M ? ar0 : g.M - 1;
+    ar1 = ar1 < g.M ? ar1 : g.M - 1;
+    f32x4 ra[2];
+    auto load_a = [&](int c) {
+        const bool s1 = c >= nc0;
+        const float* A = s1 ? A1 : A0;
+        const int lda = s1 ? lda1 : lda0;
+        const int k = (s1 ? c - nc0 : c) * SK + sq * 4;
+        ra[0] = *reinterpret_cast<const f32x4*>(A + ar0 * lda + k);
+        ra[1] = *reinterpret_cast<const f32x4*>(A + ar1 * lda + k);
+    };
+    auto store_a = [&](int buf) {
+        unsigned short* as = smem_s + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + (RM / 2) * i;
+            const int o = ((sq >> 1) ^ ((row >> 3) & 1)) * 8 + (sq & 1) * 4;
+            bf16x4 h, m, l;
+            if (g.flags & 0x400) {  // ablation: one conversion instead of the 3-term split
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = m[e] = l[e] = (__bf16)ra[i][e];
+            } else {
+                split4(ra[i], h, m, l);
+            }
+            *reinterpret_cast<bf16x4*>(as + (0 * RM + row) * SK + o) = h;
+            *reinterpret_cast<bf16x4*>(as + (1 * RM + row) * SK + o) = m;
+            *reinterpret_cast<bf16x4*>(as + (2 * RM + row) * SK + o) = l;
+        }
+    };
+    // B: 3 planes x 8 pieces (32 rows x 32 B each) per chunk; wave w issues pieces w, w+4 of every plane
+    const int dr = lane >> 1;                                      // row inside a 32-row piece
+    const int dsp = (lane & 1) ^ ((dr >> 3) & 1);                  // source 16-B piece for this lane's LDS slot
+    auto dma_b = [&](int c, int buf) {
+        const bool s1 = c >= nc0;
+        const unsigned short* P = s1 ? P1 : P0;
+        const int64_t ps = s1 ? ps1 : ps0;
+        const int ldb = s1 ? ldb1 : ldb0;
+        const int k = (s1 ? c - nc0 : c) * SK + dsp * 8;
+        unsigned short* bs = smem_s + buf * BUF + 3 * RM * SK;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4 / WM; ++j) {
+                const int piece = wid + 2 * WM * j;  // rows 32*piece .. 32*piece + 31 (N == 256: always in range)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(P + p * ps + (int64_t)(piece * 32 + dr) * ldb + k),
+                                                 (lds_ptr_t)(bs + (p * 256 + piece * 32) * SK), 16, 0, 0);
+            }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    load_a(0);
+    dma_b(0, 0);
+    store_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) {
+            if (!(g.flags & 0x800)) load_a(c + 1);  // ablation: no A loads
+            if (!(g.flags & 0x1000)) dma_b(c + 1, buf ^ 1);  // ablation: no B DMA
+        }
+        const unsigned short* as = smem_s + buf * BUF;
+        const unsigned short* bs = as + 3 * RM * SK;
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                a[tt][p] = *reinterpret_cast<const bf16x8*>(as + s3w_off(p, RM, wm * 64 + tt * 32 + fr, fh));
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[p] = *reinterpret_cast<const bf16x8*>(bs + s3w_off(p, 256, wn * 128 + tn * 32 + fr, fh));
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                f32x16 v = acc[tm][tn];
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[2], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[0], v, 0, 0, 0);
+                acc[tm][tn] = v;
+            }
+        }
+        if (c + 1 < nchunks) store_a(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    nt_epilogue_t<4, 0>(g, acc, reinterpret_cast<float*>(smem_s), m0, wn * 128, lane, wid, wm, 0);
+    nt_epilogue_t<4, 2>(g, acc, reinterpret_cast<float*>(smem_s), m0, wn * 128 + 64, lane, wid, wm, 0);
+}
+
+static int g_gemm_mode = -1;  // 0 = exact fp32 MFMA, 1 = 3-term bf16 split; -1 = read PN_GEMM_MODE on first use
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("PN_GEMM_MODE");
+        g_gemm_mode = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_gemm_mode;
+}
+extern "C" int pn_set_gemm_mode(int mode) {
+    if (mode != 0 && mode != 1) return PN_ERR_UNSUPPORTED;
+    g_gemm_mode = mode;
+    return PN_OK;
+}
+
 int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.nseg < 1 || g.nseg > 2) return PN_ERR_BAD_SHAPE;
     for (int i = 0; i < g.nseg; ++i) {
@@ -471,7 +785,20 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     if (g_dbg & 16) gg.stagger *= 2;
     bool dma = !(g_dbg & 64) && !(g.flags & 0x200);
     for (int i = 0; i < g.nseg; ++i) dma = dma && (g.seg[i].K % DK == 0);
-    if (dma) hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
+    bool split = gemm_mode() == 1 && !(g.flags & 0x200);
+    if (g_dbg & 0x1c00) gg.flags |= (g_dbg & 0x1c00);  // split-kernel ablations
+    for (int i = 0; i < g.nseg; ++i) split = split && (g.seg[i].K % SK == 0);
+    S3wArgs wa;
+    bool wide = split && g.N == 256 && !(g_dbg & 256);
+    for (int i = 0; i < g.nseg && wide; ++i)
+        wide = lookup_planes(g.seg[i].B, wa.bp[i]) && (g.seg[i].ldb % 8 == 0) &&
+               ((reinterpret_cast<uintptr_t>(wa.bp[i].base) & 15) == 0) && (wa.bp[i].stride % 8 == 0);
+    if (wide && !(g_dbg & 512)) {
+        const unsigned tiles256 = (unsigned)((g.M + 255) / 256);
+        hipLaunchKernelGGL(k_gemm_nt_s3w<4>, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
+    } else if (wide) hipLaunchKernelGGL(k_gemm_nt_s3w<2>, dim3((unsigned)tiles_m), dim3(256), 0, s, gg, wa, (int)tiles_m);
+    else if (split) hipLaunchKernelGGL(k_gemm_nt_s3, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
+    else if (dma) hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
     else hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
     PN_CHECK_LAUNCH();
     return PN_OK;

@@ -248,3 +248,40 @@ def test_state_dict_and_errors():
     with pytest.raises(RuntimeError, match="no CPU"):
         pn.MipNeRF(num_samples=8, rgb_activation="softplus")(rays=rays, randomized=False, white_bkgd=False,
                                                              use_ort_loss=False)
+
+
+def test_split_gemm_mode_parity(golden):
+    """The optional 3-term bf16-split GEMM mode (pn_set_gemm_mode(1): six v_mfma_f32_32x32x16_bf16 per product,
+    fp32 accumulate) must meet the same parity gates as the exact fp32-MFMA default."""
+    import pano_nerf_amd as pn
+    from pano_nerf_amd import _lib
+    _lib.load().pn_set_gemm_mode(1)
+    try:
+        case = "B64_N32"
+        g, s = golden("pano_full_" + case), golden("stages_" + case)
+        N = s["t_det"].shape[1] - 1
+        rays, env = to_dev(rays_of(s)), to_dev(env_of(golden))
+        model = make_pano(N)
+        with torch.no_grad():
+            outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+        check_tuple(outs, g, "val", NAMES9, g64=g)
+        model.noise_override = dict(t_rand=torch.from_numpy(g["train_t_rand"]), u_rand=torch.from_numpy(g["train_u_rand"]),
+                                    env_rand=torch.from_numpy(g["train_env_rand"]))
+        outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+        check_tuple(outs, g, "train", NAMES9)
+        loss, _ = pn.pano_loss(outs, rays.lossmult, torch.from_numpy(s["rgbs"]).to(dev()))
+        assert abs(float(loss) - float(g["train/loss"])) < 1e-4 * abs(float(g["train/loss"]))
+        loss.backward()
+        check_grads(model, g, "train")
+        # operand values across 30 binades keep fp32 accuracy (the split is exact, the dropped terms are <= 2^-24)
+        gen = torch.Generator().manual_seed(1)
+        A = torch.randn(512, 256, generator=gen) * torch.exp2(torch.randint(-15, 15, (512, 1), generator=gen).float())
+        Bt = torch.randn(256, 256, generator=gen)
+        ref = A.double() @ Bt.double().T
+        dA, dB, C = A.to(dev()), Bt.to(dev()), torch.empty(512, 256, device=dev())
+        _lib.call("pn_gemm_nt", 512, 256, 256, dA.data_ptr(), 256, dB.data_ptr(), 256, C.data_ptr(), 256, None, None, 0, 0,
+                  torch.cuda.current_stream().cuda_stream)
+        err = (C.cpu().double() - ref).abs() / (A.double().abs() @ Bt.double().abs().T)
+        assert float(err.max()) < 3e-7, float(err.max())
+    finally:
+        _lib.load().pn_set_gemm_mode(0)
