@@ -47,7 +47,6 @@ struct PnGemmNt {
     uint32_t* mask_out;         // [M, PN_MASK_WORDS]
     float* colsum;              // [2 * ceil(M/128), N] per-wave-row column sums (PN_EPI_COLSUM)
     int flags;
-    int stagger;                // set by the launcher
 };
 // dst[r*ldd + c] (+)= sum_b src[b*stride + r*src_ld + c]  for r < rows, c < cols; scratch >= 64*rows*cols floats
 int pn_launch_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols, int src_ld, float* dst,

@@ -246,9 +246,6 @@ __device__ __forceinline__ void nt_epilogue(const PnGemmNt& g, f32x16 (&acc)[2][
 #ifndef PN_NT_OCC
 #define PN_NT_OCC 3
 #endif
-#ifndef PN_NT_PREFETCH
-#define PN_NT_PREFETCH 1
-#endif
 __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tiles_n, int ntiles) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDT];
     float* As = smem;
@@ -273,16 +270,9 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
     const int arow = (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
     const int brow = (wn * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
 
-    // One tile per workgroup.  Equal-length tiles keep the three resident workgroups of a CU in lockstep
-    // (load-only prologues and store-only epilogues coincide and idle the MFMA pipes), so the workgroups of
-    // the first residency round start a third of a tile apart; later workgroups inherit the offsets.
     const int t = xcd_remap(blockIdx.x, ntiles);
     const int64_t m0 = (int64_t)(t / tiles_n) * BM;
     const int n0 = (t % tiles_n) * BN;
-    if (blockIdx.x < 768 && g.stagger > 0) {
-        const int slot = blockIdx.x / 256;  // which of the CU's resident workgroups (speed only)
-        for (int i = 0; i < slot * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -314,31 +304,6 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
             }
         }
     };
-#if PN_NT_PREFETCH == 2
-    // two K-chunks in flight in registers (rA: odd chunks, rB: even chunks), one staged in LDS
-    NtRegs rA, rB;
-    nt_load(A0, lda0, B0, ldb0, K0, Mrows, Ncols, 0, m0, n0, tid, rB);
-    nt_store(As, Bs, tid, rB);
-    issue_load(1, rA);
-    issue_load(2, rB);
-    __syncthreads();
-    for (int c = 0; c < nchunks; c += 2) {
-        compute();  // chunk c
-        __syncthreads();
-        if (c + 1 < nchunks) {
-            nt_store(As, Bs, tid, rA);  // chunk c+1
-            __syncthreads();
-            issue_load(c + 3, rA);
-            compute();
-            __syncthreads();
-            if (c + 2 < nchunks) {
-                nt_store(As, Bs, tid, rB);  // chunk c+2
-                __syncthreads();
-                issue_load(c + 4, rB);
-            }
-        }
-    }
-#else
     NtRegs regs;
     nt_load(A0, lda0, B0, ldb0, K0, Mrows, Ncols, 0, m0, n0, tid, regs);
     nt_store(As, Bs, tid, regs);
@@ -352,7 +317,6 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
             __syncthreads();
         }
     }
-#endif
 
     nt_epilogue(g, acc, smem, m0, n0, lane, wid, wm, wn);
 }
@@ -779,10 +743,6 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     for (int i = 0; i < g.nseg; ++i) ksum += g.seg[i].K;
     ProfScope prof(0, 2.0 * (double)g.M * g.N * ksum, s);
     PnGemmNt gg = g;
-    // stagger unit: ~1/3 of the time three co-resident tiles take, in s_sleep(127) quanta (8128 cycles each)
-    double tile_cycles = 3.0 * 64.0 * 64.0 * ((ksum + BK - 1) / BK);
-    gg.stagger = (nwg > 768 && !(g_dbg & 8)) ? (int)(tile_cycles / 3.0 / 8128.0 + 0.5) : 0;
-    if (g_dbg & 16) gg.stagger *= 2;
     bool dma = !(g_dbg & 64) && !(g.flags & 0x200);
     for (int i = 0; i < g.nseg; ++i) dma = dma && (g.seg[i].K % DK == 0);
     bool split = gemm_mode() == 1 && !(g.flags & 0x200);
@@ -1198,6 +1158,176 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tn_wide(PnTnArgs g, int tiles2,
         }
 }
 
+// ---- TN on the bf16 matrix cores with fp32 accuracy (3-term split, see k_gemm_nt_s3) ----------------------
+// Both operands are activations, so both are split in the staging path.  The MFMA wants 8 consecutive k (= rows)
+// per lane; the planes are therefore stored k-pair-major: word [kp][col] holds rows 2kp, 2kp+1 of one column as
+// two bf16 (one v_cvt_pk_bf16_f32 packs them), a thread writes its 4 columns with one ds_write_b128 per plane and
+// a fragment is four conflict-free ds_read_b32 (k-pairs 4h .. 4h+3).  16-row chunks, two LDS buffers, one barrier
+// per chunk; row / column tails are zero-filled by selects, so one kernel serves every shape.
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    unsigned u;
+    __builtin_memcpy(&u, &v, 4);
+    return u;
+}
+// exact 3-term split of two floats (rows k, k+1 of one column) into three packed words
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16(r0, r1);
+    r0 -= __uint_as_float(m << 16);
+    r1 -= __uint_as_float(m & 0xffff0000u);
+    l = pack_bf16(r0, r1);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 3) void k_gemm_tn_s3(PnTnArgs g, int tiles2, int ntiles, int nsplit) {
+    // per buffer: X planes [3][8 kp][128 cols] u32 (12 KB), Y planes (12 KB)
+    __shared__ __attribute__((aligned(16))) unsigned smem_u[2 * 2 * 3 * 8 * 128];  // 48 KB
+    constexpr int OP = 3 * 8 * 128, BUFW = 2 * OP;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
+    const int tile = jj % ntiles;
+    const int64_t split = (int64_t)(jj / ntiles) * 8 + xcd;
+    if (split >= nsplit) return;
+    const int i0 = (tile / tiles2) * BM, j0 = (tile % tiles2) * BN;
+    const int64_t c_begin = split * (g.rows_per_split / BK);
+    int64_t c_end = c_begin + g.rows_per_split / BK;
+    if (c_end > g.chunks_total) c_end = g.chunks_total;
+
+    const float* const X0 = g.seg[0].X;
+    const float* const Y0 = g.seg[0].Y;
+    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
+    const int64_t M0 = g.seg[0].M;
+    const float* const X1 = g.seg[1].X;
+    const float* const Y1 = g.seg[1].Y;
+    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
+    const int64_t M1 = g.seg[1].M;
+    const int64_t chunks0 = g.chunks0;
+    const int N1 = g.N1, N2 = g.N2;
+
+    // staging: thread -> columns 4cg .. 4cg+3, k-pair rg (rows 2rg, 2rg+1 of the 16-row sub-chunk)
+    const int cg = tid & 31, rg = tid >> 5;
+    const bool xin = i0 + 4 * cg < N1, yin = j0 + 4 * cg < N2;
+    const int xc = xin ? i0 + 4 * cg : 0, yc = yin ? j0 + 4 * cg : 0;
+    f32x4 rx[2], ry[2];
+    auto load = [&](int64_t sc) {  // sub-chunk sc = 2 * chunk + half
+        const int64_t c = sc >> 1;
+        const bool s1 = c >= chunks0;
+        const float* X = s1 ? X1 : X0;
+        const float* Y = s1 ? Y1 : Y0;
+        const int ldx = s1 ? ldx1 : ldx0, ldy = s1 ? ldy1 : ldy0;
+        const int64_t Mseg = s1 ? M1 : M0;
+        const int64_t r0 = (s1 ? c - chunks0 : c) * BK + (sc & 1) * 16 + 2 * rg;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t r = r0 + i;
+            const bool rin = r < Mseg;
+            const int64_t rc = rin ? r : Mseg - 1;
+            f32x4 vx = *reinterpret_cast<const f32x4*>(X + rc * ldx + xc);
+            f32x4 vy = *reinterpret_cast<const f32x4*>(Y + rc * ldy + yc);
+            rx[i] = (rin && xin) ? vx : z;
+            ry[i] = (rin && yin) ? vy : z;
+        }
+    };
+    auto store = [&](int buf) {
+        unsigned* xs = smem_u + buf * BUFW;
+        unsigned* ys = xs + OP;
+        u32x4 h, m, l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned th, tm_, tl;
+            split_pair(rx[0][c], rx[1][c], th, tm_, tl);
+            h[c] = th;
+            m[c] = tm_;
+            l[c] = tl;
+        }
+        *reinterpret_cast<u32x4*>(xs + (0 * 8 + rg) * 128 + 4 * cg) = h;
+        *reinterpret_cast<u32x4*>(xs + (1 * 8 + rg) * 128 + 4 * cg) = m;
+        *reinterpret_cast<u32x4*>(xs + (2 * 8 + rg) * 128 + 4 * cg) = l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned th, tm_, tl;
+            split_pair(ry[0][c], ry[1][c], th, tm_, tl);
+            h[c] = th;
+            m[c] = tm_;
+            l[c] = tl;
+        }
+        *reinterpret_cast<u32x4*>(ys + (0 * 8 + rg) * 128 + 4 * cg) = h;
+        *reinterpret_cast<u32x4*>(ys + (1 * 8 + rg) * 128 + 4 * cg) = m;
+        *reinterpret_cast<u32x4*>(ys + (2 * 8 + rg) * 128 + 4 * cg) = l;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int64_t s_begin = 2 * c_begin, s_end = 2 * c_end;
+    if (s_begin < s_end) {
+        load(s_begin);
+        store(0);
+        __syncthreads();
+        const int fr = lane & 31, fh = lane >> 5;
+        for (int64_t sc = s_begin; sc < s_end; ++sc) {
+            const int buf = (int)((sc - s_begin) & 1);
+            if (sc + 1 < s_end) load(sc + 1);
+            const unsigned* xs = smem_u + buf * BUFW;
+            const unsigned* ys = xs + OP;
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    u32x4 va, vb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        va[q] = xs[(p * 8 + 4 * fh + q) * 128 + wm * 64 + tt * 32 + fr];
+                        vb[q] = ys[(p * 8 + 4 * fh + q) * 128 + wn * 64 + tt * 32 + fr];
+                    }
+                    __builtin_memcpy(&a[tt][p], &va, 16);
+                    __builtin_memcpy(&b[tt][p], &vb, 16);
+                }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    f32x16 v = acc[tm][tn];
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], v, 0, 0, 0);
+                    acc[tm][tn] = v;
+                }
+            if (sc + 1 < s_end) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* out = g.slab + split * (int64_t)g.N1 * g.N2;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = j0 + wn * 64 + tn * 32 + (lane & 31);
+            if (col >= g.N2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.N1) out[(int64_t)row * g.N2 + col] = acc[tm][tn][r];
+            }
+        }
+}
+
 // Deterministic sum over a leading "partials" dimension: out[e] = sum_b src[b*stride + e'] for the
 // elements e of a [rows, cols] block.  One block = 64 elements x 4 partial lanes; grid.y splits the partials.
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols,
@@ -1295,7 +1425,10 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
     g.N2 = N2;
     g.chunks0 = (segs[0].M + BK - 1) / BK;
     g.chunks_total = g.chunks0 + (nseg > 1 ? (segs[1].M + BK - 1) / BK : 0);
-    const bool wide = (N1 % 128 == 0) && (N2 % 256 == 0) && !(g_dbg & 128);
+    // the split TN kernel is correct but slower than the fp32-MFMA ones (both operands are split on the fly and the
+    // k-pair-major fragments cost four ds_read_b32 each): opt-in for experiments only (ablation bit 2048)
+    const bool s3 = gemm_mode() == 1 && (g_dbg & 2048);
+    const bool wide = !s3 && (N1 % 128 == 0) && (N2 % 256 == 0) && !(g_dbg & 128);
     int nsplit = tn_splits(Mtotal, N1, N2);
     int64_t per = (g.chunks_total + nsplit - 1) / nsplit;
     g.rows_per_split = per * BK;
@@ -1306,7 +1439,9 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
         const int ntiles = tiles1 * tiles2;
         const int groups = (nsplit + 7) / 8;
         const bool full = (N1 % BM == 0) && (N2 % BN == 0) && !(g_dbg & 32);
-        if (wide) {
+        if (s3) {
+            hipLaunchKernelGGL(k_gemm_tn_s3, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
+        } else if (wide) {
             const int t2 = N2 / 256, nt2 = (N1 / 128) * t2;
             hipLaunchKernelGGL(k_gemm_tn_wide, dim3(groups * nt2 * 8), dim3(256), 0, s, g, t2, nt2, nsplit);
         } else if (full) hipLaunchKernelGGL(k_gemm_tn_dma, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
