@@ -133,14 +133,23 @@ int pn_density_grad(int64_t M, int num_density_channels, float density_bias, con
  *     softplus'' term internally);
  *   d_mean [M,3] or null: if non-null receives d loss / d mean (first-order, env-light path).
  * work: scratch of pn_mlp_backward_work_floats(M, view_rows) floats.
+ * Batching the weight gradients of one training step: the evaluations of a step (env light, level 1, level 0) share
+ * the weights, so their trunk / extra-layer weight gradients are ONE TN GEMM per layer over all their rows.  Calls with
+ * defer_wgrad = 1 skip those GEMMs and leave their operands in `work` (keep it alive); the last call passes
+ * n_deferred (<= 2) and, per deferred evaluation, its M, enc, acts, rsweep (or null), work and whether it ran the
+ * tangent sweep (host arrays), and reduces everything.  M_batched = total rows of those GEMMs (own + deferred, tangent
+ * rows counted) sizes the slab part of `work` (0 = stand-alone).
  * side_stream (nullable): a second hipStream_t; when given, the weight-gradient GEMMs / reductions run there,
  * forked from and joined back to `stream` with events inside the call, so they overlap the data-gradient chain. */
-int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows);
+int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows, int64_t M_batched);
 int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, float density_bias,
                     const float* params, const float* wpack, const float* mean, const float* cov,
                     const float* enc, const float* viewenc, const float* acts, const uint32_t* masks,
                     const float* raw_density, const float* d_raw_rgb, const float* d_raw_density,
                     const float* rsweep, const float* v_gradmean, float* d_mean, float* grads, float* work,
+                    int64_t M_batched, int defer_wgrad, int n_deferred, const int64_t* dM_host,
+                    const float* const* denc_host, const float* const* dacts_host,
+                    const float* const* drsweep_host, float* const* dwork_host, const int* dtangent_host,
                     void* stream, void* side_stream);
 
 /* ---- volumetric rendering ---------------------------------------------------------

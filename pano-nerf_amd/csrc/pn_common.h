@@ -61,8 +61,9 @@ struct PnSegTn {
 };
 // C[N1, N2] (ldc) (+)= sum_seg X^T Y ; work >= pn_tn_work_floats(...)
 int64_t pn_tn_work_floats(int64_t Mtotal, int N1, int N2);
+// work_avail: floats available at `work` (< 0: unknown, trust the caller); an undersized slab is refused on the host
 int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, int ldc, int accumulate, float* work,
-                      hipStream_t s);
+                      int64_t work_avail, hipStream_t s);
 
 // bf16 split planes of the weight blocks (pn_gemm.hip keeps the registry; pn_mlp.hip fills the planes)
 void pn_register_planes(int which, const float* fbase, int64_t nfloats, const unsigned short* planes);

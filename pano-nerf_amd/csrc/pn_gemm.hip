@@ -787,15 +787,47 @@ extern "C" int pn_mfma_probe(float* out, int blocks, int iters, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------- TN
+#define TN_MAXSEG 4
 struct PnTnArgs {
-    PnSegTn seg[2];
+    PnSegTn seg[TN_MAXSEG];
     int nseg;
     int N1, N2;
     int64_t rows_per_split;  // multiple of BK
-    int64_t chunks0;         // number of 32-row chunks of segment 0 (segment 1 follows)
+    int64_t cum[TN_MAXSEG + 1];  // first 32-row chunk of every segment; cum[nseg..] = chunks_total
     int64_t chunks_total;
     float* slab;             // [nsplit][N1][N2]
 };
+// A workgroup walks consecutive chunks, so the segment a chunk belongs to changes at most 3 times: keep the current
+// segment's operands in scalars and re-read the kernel-argument table only when a boundary is crossed (a table
+// lookup per chunk costs scalar loads whose s_waitcnt lgkmcnt(0) also drains the LDS reads, or ~30 live SGPRs).
+struct TnCursor {
+    const float* X;
+    const float* Y;
+    int ldx, ldy, seg;
+    int64_t M, c0, c_end;
+};
+__device__ __forceinline__ void tn_cursor_load(const PnTnArgs& g, TnCursor& t, int seg) {
+    t.seg = seg;
+    t.X = g.seg[seg].X;
+    t.Y = g.seg[seg].Y;
+    t.ldx = g.seg[seg].ldx;
+    t.ldy = g.seg[seg].ldy;
+    t.M = g.seg[seg].M;
+    t.c0 = g.cum[seg];
+    t.c_end = g.cum[seg + 1];
+}
+__device__ __forceinline__ void tn_cursor_init(const PnTnArgs& g, TnCursor& t, int64_t c) {
+    int seg = 0;
+    if (c >= g.cum[1]) seg = 1;
+    if (c >= g.cum[2]) seg = 2;
+    if (c >= g.cum[3]) seg = 3;
+    tn_cursor_load(g, t, seg);
+}
+// advance to the segment holding chunk c (c never decreases); returns the first row of the chunk in its segment
+__device__ __forceinline__ int64_t tn_cursor_seek(const PnTnArgs& g, TnCursor& t, int64_t c) {
+    while (c >= t.c_end && t.seg < TN_MAXSEG - 1) tn_cursor_load(g, t, t.seg + 1);
+    return (c - t.c0) * BK;
+}
 
 struct TnRegs {
     f32x4 x[4], y[4];
@@ -857,20 +889,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2, int nti
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const float* const X0 = g.seg[0].X;
-    const float* const Y0 = g.seg[0].Y;
-    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
-    const int64_t M0 = g.seg[0].M;
-    const float* const X1 = g.seg[1].X;
-    const float* const Y1 = g.seg[1].Y;
-    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
-    const int64_t M1 = g.seg[1].M;
-    const int64_t chunks0 = g.chunks0;
     const int N1 = g.N1, N2 = g.N2;
+    TnCursor cur;
+    tn_cursor_init(g, cur, c_begin);
     auto load_chunk = [&](int64_t c, TnRegs& regs) {
-        const bool s1 = c >= chunks0;
-        tn_load(s1 ? X1 : X0, s1 ? ldx1 : ldx0, s1 ? Y1 : Y0, s1 ? ldy1 : ldy0, s1 ? M1 : M0, N1, N2,
-                (s1 ? c - chunks0 : c) * BK, i0, j0, tid, regs);
+        const int64_t r0 = tn_cursor_seek(g, cur, c);
+        tn_load(cur.X, cur.ldx, cur.Y, cur.ldy, cur.M, N1, N2, r0, i0, j0, tid, regs);
     };
     if (c_begin < c_end) {
         TnRegs regs;
@@ -912,127 +936,6 @@ __global__ __launch_bounds__(256) void k_gemm_tn(PnTnArgs g, int tiles2, int nti
         }
 }
 
-// ---- TN with LDS-DMA staging (full 128x128 tiles only) ---------------------------------------------
-// global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KiB contiguously into LDS, so the [32][128] chunk image
-// is filled row-pair by row-pair with no staging registers and no ds_write; two LDS buffers keep the next
-// chunk's DMA in flight under the current chunk's MFMAs with ONE barrier per chunk.
-
-__global__ __launch_bounds__(256) void k_gemm_tn_dma(PnTnArgs g, int tiles2, int ntiles, int nsplit) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * BM];  // [buf][X|Y][32][128] = 64 KB
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
-    const int tile = jj % ntiles;
-    const int64_t split = (int64_t)(jj / ntiles) * 8 + xcd;
-    if (split >= nsplit) return;
-    const int i0 = (tile / tiles2) * BM, j0 = (tile % tiles2) * BN;
-    const int64_t c_begin = split * (g.rows_per_split / BK);
-    int64_t c_end = c_begin + g.rows_per_split / BK;
-    if (c_end > g.chunks_total) c_end = g.chunks_total;
-
-    const float* const X0 = g.seg[0].X;
-    const float* const Y0 = g.seg[0].Y;
-    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
-    const int64_t M0 = g.seg[0].M;
-    const float* const X1 = g.seg[1].X;
-    const float* const Y1 = g.seg[1].Y;
-    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
-    const int64_t M1 = g.seg[1].M;
-    const int64_t chunks0 = g.chunks0;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // each wave issues 4 X pieces + 4 Y pieces per chunk; piece p covers rows 2p, 2p+1 (lane -> row, 16-B column)
-    auto stage = [&](int64_t c, int buf) {
-        const bool s1 = c >= chunks0;
-        const float* X = s1 ? X1 : X0;
-        const float* Y = s1 ? Y1 : Y0;
-        const int ldx = s1 ? ldx1 : ldx0, ldy = s1 ? ldy1 : ldy0;
-        const int64_t Mseg = s1 ? M1 : M0;
-        const int64_t r0 = (s1 ? c - chunks0 : c) * BK;
-        float* xs = smem + buf * (2 * BK * BM);
-        float* ys = xs + BK * BM;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int piece = wid * 4 + p;              // 0..15
-            const int row = piece * 2 + (lane >> 5);    // 0..31
-            int64_t gr = r0 + row;
-            gr = gr < Mseg ? gr : Mseg - 1;             // clamped; tail rows are zeroed after landing
-            const int col = (lane & 31) * 4;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(X + gr * ldx + i0 + col), (lds_ptr_t)(xs + piece * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Y + gr * ldy + j0 + col), (lds_ptr_t)(ys + piece * 256), 16, 0, 0);
-        }
-    };
-    auto valid_rows = [&](int64_t c) -> int {
-        const bool s1 = c >= chunks0;
-        const int64_t Mseg = s1 ? M1 : M0;
-        const int64_t r0 = (s1 ? c - chunks0 : c) * BK;
-        const int64_t v = Mseg - r0;
-        return v >= BK ? BK : (int)v;
-    };
-
-    if (c_begin < c_end) {
-        stage(c_begin, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // one ds_read_b64 per operand and k-step: a lane takes columns 2i and 2i+1 of its wave's 64, i.e. MFMA
-        // tile tm covers the stride-2 column set {2i + tm} (the epilogue un-permutes)
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const int xo = (lane >> 5) * BM + wm * 64 + 2 * (lane & 31);
-        const int yo = (lane >> 5) * BM + wn * 64 + 2 * (lane & 31);
-        for (int64_t c = c_begin; c < c_end; ++c) {
-            const int buf = (int)((c - c_begin) & 1);
-            float* Xs = smem + buf * (2 * BK * BM);
-            float* Ys = Xs + BK * BM;
-            const int vr = valid_rows(c);
-            if (vr < BK) {  // ragged tail of a segment: zero the rows past the end (uniform branch)
-                for (int e = tid; e < (BK - vr) * BM; e += 256) {
-                    Xs[vr * BM + e] = 0.f;
-                    Ys[vr * BM + e] = 0.f;
-                }
-                __syncthreads();
-            }
-            if (c + 1 < c_end) stage(c + 1, buf ^ 1);
-            f32x2 a = *reinterpret_cast<const f32x2*>(Xs + xo);
-            f32x2 b = *reinterpret_cast<const f32x2*>(Ys + yo);
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                f32x2 an = a, bn = b;
-                if (kk + 1 < BK / 2) {  // fetch the next k-step's operands before this step's MFMAs
-                    an = *reinterpret_cast<const f32x2*>(Xs + xo + (kk + 1) * 2 * BM);
-                    bn = *reinterpret_cast<const f32x2*>(Ys + yo + (kk + 1) * 2 * BM);
-                }
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[0], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc[1][1], 0, 0, 0);
-                a = an;
-                b = bn;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's DMA has landed (this wave's part)
-            __syncthreads();
-        }
-    }
-    float* out = g.slab + split * (int64_t)g.N1 * g.N2;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = j0 + wn * 64 + 2 * (lane & 31) + tn;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + tm;
-                out[(int64_t)row * g.N2 + col] = acc[tm][tn][r];
-            }
-        }
-}
-
 // ---- TN, 128 x 256 output tile (weight gradients of the 256 x 256 layers) ---------------------------------
 // 4 waves, each a 128 x 64 slab = 4 x 2 MFMA tiles (128 accumulator registers): per k-step ONE ds_read_b128 of X
 // (columns 4i..4i+3 -> tile tm covers the stride-4 set {4i + tm}) and ONE ds_read_b64 of Y feed 8 MFMAs, half the
@@ -1050,16 +953,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tn_wide(PnTnArgs g, int tiles2,
     int64_t c_end = c_begin + g.rows_per_split / BK;
     if (c_end > g.chunks_total) c_end = g.chunks_total;
 
-    const float* const X0 = g.seg[0].X;
-    const float* const Y0 = g.seg[0].Y;
-    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
-    const int64_t M0 = g.seg[0].M;
-    const float* const X1 = g.seg[1].X;
-    const float* const Y1 = g.seg[1].Y;
-    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
-    const int64_t M1 = g.seg[1].M;
-    const int64_t chunks0 = g.chunks0;
-
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1068,23 +961,16 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tn_wide(PnTnArgs g, int tiles2,
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto seg_of = [&](int64_t sc, const float*& X, const float*& Y, int& ldx, int& ldy, int64_t& Mseg, int64_t& r0) {
-        const int64_t c = sc >> 1;
-        const bool s1 = c >= chunks0;
-        X = s1 ? X1 : X0;
-        Y = s1 ? Y1 : Y0;
-        ldx = s1 ? ldx1 : ldx0;
-        ldy = s1 ? ldy1 : ldy0;
-        Mseg = s1 ? M1 : M0;
-        r0 = (s1 ? c - chunks0 : c) * BK + (sc & 1) * TW;
-    };
     // X sub-chunk [16][128]: 8 pieces of 2 rows; Y sub-chunk [16][256]: 16 pieces of 1 row.  Wave w: X pieces 2w, 2w+1
-    // and Y pieces 4w .. 4w+3.
-    auto stage = [&](int64_t sc, int buf) {
-        const float *X, *Y;
-        int ldx, ldy;
-        int64_t Mseg, r0;
-        seg_of(sc, X, Y, ldx, ldy, Mseg, r0);
+    // and Y pieces 4w .. 4w+3.  stage() returns the number of valid rows of the sub-chunk it issued.
+    TnCursor cur;
+    tn_cursor_init(g, cur, c_begin);
+    auto stage = [&](int64_t sc, int buf) -> int {
+        const int64_t r0 = tn_cursor_seek(g, cur, sc >> 1) + (sc & 1) * TW;
+        const float* X = cur.X;
+        const float* Y = cur.Y;
+        const int ldx = cur.ldx, ldy = cur.ldy;
+        const int64_t Mseg = cur.M;
         float* xs = smem + buf * (TW * 384);
         float* ys = xs + TW * 128;
 #pragma unroll
@@ -1101,19 +987,13 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tn_wide(PnTnArgs g, int tiles2,
             gr = gr < Mseg ? gr : Mseg - 1;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Y + gr * ldy + j0 + lane * 4), (lds_ptr_t)(ys + piece * 256), 16, 0, 0);
         }
-    };
-    auto valid_rows = [&](int64_t sc) -> int {
-        const float *X, *Y;
-        int ldx, ldy;
-        int64_t Mseg, r0;
-        seg_of(sc, X, Y, ldx, ldy, Mseg, r0);
         const int64_t v = Mseg - r0;
         return v >= TW ? TW : (v < 0 ? 0 : (int)v);
     };
 
     const int64_t s_begin = 2 * c_begin, s_end = 2 * c_end;
     if (s_begin < s_end) {
-        stage(s_begin, 0);
+        int vr_next = stage(s_begin, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1123,13 +1003,13 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tn_wide(PnTnArgs g, int tiles2,
             const int buf = (int)((sc - s_begin) & 1);
             float* Xs = smem + buf * (TW * 384);
             float* Ys = Xs + TW * 128;
-            const int vr = valid_rows(sc);
+            const int vr = vr_next;
             if (vr < TW) {  // ragged tail of a segment: zero the rows past the end (uniform branch)
                 for (int e = tid; e < (TW - vr) * 128; e += 256) Xs[vr * 128 + e] = 0.f;
                 for (int e = tid; e < (TW - vr) * 256; e += 256) Ys[vr * 256 + e] = 0.f;
                 __syncthreads();
             }
-            if (sc + 1 < s_end) stage(sc + 1, buf ^ 1);
+            if (sc + 1 < s_end) vr_next = stage(sc + 1, buf ^ 1);
 #pragma unroll
             for (int kk = 0; kk < TW / 2; ++kk) {
                 f32x4 a = *reinterpret_cast<const f32x4*>(Xs + xo + kk * 2 * 128);
@@ -1199,30 +1079,21 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tn_s3(PnTnArgs g, int tiles2, i
     int64_t c_end = c_begin + g.rows_per_split / BK;
     if (c_end > g.chunks_total) c_end = g.chunks_total;
 
-    const float* const X0 = g.seg[0].X;
-    const float* const Y0 = g.seg[0].Y;
-    const int ldx0 = g.seg[0].ldx, ldy0 = g.seg[0].ldy;
-    const int64_t M0 = g.seg[0].M;
-    const float* const X1 = g.seg[1].X;
-    const float* const Y1 = g.seg[1].Y;
-    const int ldx1 = g.seg[1].ldx, ldy1 = g.seg[1].ldy;
-    const int64_t M1 = g.seg[1].M;
-    const int64_t chunks0 = g.chunks0;
     const int N1 = g.N1, N2 = g.N2;
 
+    TnCursor cur;
+    tn_cursor_init(g, cur, c_begin);
     // staging: thread -> columns 4cg .. 4cg+3, k-pair rg (rows 2rg, 2rg+1 of the 16-row sub-chunk)
     const int cg = tid & 31, rg = tid >> 5;
     const bool xin = i0 + 4 * cg < N1, yin = j0 + 4 * cg < N2;
     const int xc = xin ? i0 + 4 * cg : 0, yc = yin ? j0 + 4 * cg : 0;
     f32x4 rx[2], ry[2];
     auto load = [&](int64_t sc) {  // sub-chunk sc = 2 * chunk + half
-        const int64_t c = sc >> 1;
-        const bool s1 = c >= chunks0;
-        const float* X = s1 ? X1 : X0;
-        const float* Y = s1 ? Y1 : Y0;
-        const int ldx = s1 ? ldx1 : ldx0, ldy = s1 ? ldy1 : ldy0;
-        const int64_t Mseg = s1 ? M1 : M0;
-        const int64_t r0 = (s1 ? c - chunks0 : c) * BK + (sc & 1) * 16 + 2 * rg;
+        const int64_t r0 = tn_cursor_seek(g, cur, sc >> 1) + (sc & 1) * 16 + 2 * rg;
+        const float* X = cur.X;
+        const float* Y = cur.Y;
+        const int ldx = cur.ldx, ldy = cur.ldy;
+        const int64_t Mseg = cur.M;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1402,34 +1273,46 @@ static int tn_splits(int64_t Mtotal, int N1, int N2) {
     return (int)((chunks + per - 1) / per);
 }
 
+// Upper bound of tn_splits over every row count <= Mtotal (tn_splits itself is not monotone in Mtotal: crossing a
+// multiple of `want` chunks raises the chunks per split and LOWERS the split count), with up to TN_MAXSEG segments.
 int64_t pn_tn_work_floats(int64_t Mtotal, int N1, int N2) {
-    return (int64_t)tn_splits(Mtotal, N1, N2) * N1 * N2;
+    int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
+    int64_t want = (1024 + tiles - 1) / tiles;
+    if ((N1 % 128 == 0) && (N2 % 256 == 0)) want = 768 / ((N1 / 128) * (N2 / 256));
+    if (want < 1) want = 1;
+    const int64_t chunks = (Mtotal + BK - 1) / BK + 1;
+    int64_t bound = (chunks + 3) / 4;
+    if (bound > want) bound = want;
+    if (bound < 1) bound = 1;
+    return bound * N1 * N2;
 }
 
 int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, int ldc, int accumulate, float* work,
-                      hipStream_t s) {
-    if (nseg < 1 || nseg > 2 || N1 <= 0 || N2 <= 0) return PN_ERR_BAD_SHAPE;
+                      int64_t work_avail, hipStream_t s) {
+    if (nseg < 1 || nseg > TN_MAXSEG || N1 <= 0 || N2 <= 0) return PN_ERR_BAD_SHAPE;
     if (!C || !work) return PN_ERR_NULL;
     PnTnArgs g;
     g.nseg = nseg;
-    int64_t Mtotal = 0;
-    for (int i = 0; i < nseg; ++i) {
-        g.seg[i] = segs[i];
+    int64_t Mtotal = 0, chunks = 0;
+    for (int i = 0; i < TN_MAXSEG; ++i) {
+        g.seg[i] = segs[i < nseg ? i : 0];
+        g.cum[i] = chunks;
+        if (i >= nseg) continue;
         if (segs[i].M <= 0 || (segs[i].ldx & 3) || (segs[i].ldy & 3) || !segs[i].X || !segs[i].Y) return PN_ERR_BAD_SHAPE;
         if ((reinterpret_cast<uintptr_t>(segs[i].X) & 15) || (reinterpret_cast<uintptr_t>(segs[i].Y) & 15)) return PN_ERR_BAD_SHAPE;
         Mtotal += segs[i].M;
+        chunks += (segs[i].M + BK - 1) / BK;
     }
-    if (nseg == 1) g.seg[1] = g.seg[0];
+    g.cum[TN_MAXSEG] = chunks;
+    for (int i = nseg; i < TN_MAXSEG; ++i) g.cum[i] = chunks;
     if ((N1 & 3) || (N2 & 3)) return PN_ERR_BAD_SHAPE;
     g.N1 = N1;
     g.N2 = N2;
-    g.chunks0 = (segs[0].M + BK - 1) / BK;
-    g.chunks_total = g.chunks0 + (nseg > 1 ? (segs[1].M + BK - 1) / BK : 0);
-    // the split TN kernel is correct but slower than the fp32-MFMA ones (both operands are split on the fly and the
-    // k-pair-major fragments cost four ds_read_b32 each): opt-in for experiments only (ablation bit 2048)
-    const bool s3 = gemm_mode() == 1 && (g_dbg & 2048);
+    g.chunks_total = chunks;
+    const bool s3 = gemm_mode() == 1 && (g_dbg & 2048);  // split TN: correct but slower than fp32 MFMA, experiments only
     const bool wide = !s3 && (N1 % 128 == 0) && (N2 % 256 == 0) && !(g_dbg & 128);
     int nsplit = tn_splits(Mtotal, N1, N2);
+    if (work_avail >= 0 && (int64_t)nsplit * N1 * N2 > work_avail) return PN_ERR_BAD_SHAPE;  // slab too small
     int64_t per = (g.chunks_total + nsplit - 1) / nsplit;
     g.rows_per_split = per * BK;
     g.slab = work;
@@ -1438,14 +1321,12 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
         ProfScope prof(1, 2.0 * (double)Mtotal * N1 * N2, s);
         const int ntiles = tiles1 * tiles2;
         const int groups = (nsplit + 7) / 8;
-        const bool full = (N1 % BM == 0) && (N2 % BN == 0) && !(g_dbg & 32);
         if (s3) {
             hipLaunchKernelGGL(k_gemm_tn_s3, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
         } else if (wide) {
             const int t2 = N2 / 256, nt2 = (N1 / 128) * t2;
             hipLaunchKernelGGL(k_gemm_tn_wide, dim3(groups * nt2 * 8), dim3(256), 0, s, g, t2, nt2, nsplit);
-        } else if (full) hipLaunchKernelGGL(k_gemm_tn_dma, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
-        else hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
+        } else hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
     }
     PN_CHECK_LAUNCH();
     return pn_launch_reduce_rows(work, nsplit, (int64_t)N1 * N2, N1, N2, N2, C, ldc, accumulate, nullptr, s);

@@ -18,10 +18,20 @@
 #include <vector>
 
 #define ST(s) ((hipStream_t)(s))
-#define RUN(x)                  \
-    do {                        \
-        int rc_ = (x);          \
-        if (rc_ != PN_OK) return rc_; \
+// PN_DEBUG_SYNC=1: synchronise the device after every step of the MLP entry points and name the step on stderr, so
+// an asynchronous fault is attributed to the launch that caused it (debugging aid; never set in production)
+static bool debug_sync() {
+    static const bool on = getenv("PN_DEBUG_SYNC") != nullptr;
+    return on;
+}
+#define RUN(x)                                                                 \
+    do {                                                                       \
+        int rc_ = (x);                                                         \
+        if (rc_ != PN_OK) return rc_;                                          \
+        if (debug_sync()) {                                                    \
+            fprintf(stderr, "[pn] %s:%d %s\n", __func__, __LINE__, #x);        \
+            if (hipDeviceSynchronize() != hipSuccess) return PN_ERR_HIP;       \
+        }                                                                      \
     } while (0)
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
@@ -366,9 +376,9 @@ static int colsum_into(int64_t M, const float* X, int ldx, int N, float* dst, fl
     return pn_launch_reduce_rows(partial, nb, N, 1, N, N, dst, N, 1, partial + (int64_t)nb * N, s);
 }
 static int wgrad(int64_t M, const float* X, int ldx, int N1, const float* Y, int ldy, int N2, float* dW, int ldw,
-                 float* work, hipStream_t s) {
+                 float* work, int64_t work_avail, hipStream_t s) {
     PnSegTn sg{X, Y, ldx, ldy, M};
-    return pn_launch_gemm_tn(&sg, 1, N1, N2, dW, ldw, 1, work, s);
+    return pn_launch_gemm_tn(&sg, 1, N1, N2, dW, ldw, 1, work, work_avail, s);
 }
 
 
@@ -549,17 +559,50 @@ struct EventRing {
     }
 };
 
-int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows) {
+// layout of the first part of the pn_mlp_backward workspace: the buffers a LATER call reads when the weight
+// gradients of this evaluation are deferred (batched with other evaluations of the same step)
+struct BwdKeep {
+    float *dbuf, *tbuf, *dbott, *edot;
+    int64_t Mp;
+    float* delta(int l) const { return dbuf + (int64_t)l * Mp * PN_WIDTH; }  // l = 0..7; 8 = head addend
+    float* tang(int l) const { return tbuf + (int64_t)l * Mp * PN_WIDTH; }
+};
+static BwdKeep carve_keep(float* work, int64_t Mp, float** rest) {
+    BwdKeep k;
+    k.Mp = Mp;
+    float* w = work;
+    k.dbuf = w; w += 9 * Mp * PN_WIDTH;
+    k.tbuf = w; w += 8 * Mp * PN_WIDTH;
+    k.dbott = w; w += Mp * PN_WIDTH;
+    k.edot = w; w += Mp * PN_ENC_DIM;
+    if (rest) *rest = w;
+    return k;
+}
+
+// split-K slabs shared by every weight-gradient GEMM of one call: the largest of the shapes launched
+static int64_t slab_floats(int64_t rows) {
+    const int shapes[4][2] = {{PN_WIDTH, PN_WIDTH}, {PN_WIDTH, PN_ENC_DIM}, {PN_WIDTH_COND, PN_WIDTH}, {PN_WIDTH_COND, 32}};
+    int64_t n = 0;
+    for (auto& sh : shapes) {
+        const int64_t f = pn_tn_work_floats(rows, sh[0], sh[1]);
+        if (f > n) n = f;
+    }
+    return n;
+}
+
+int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows, int64_t M_batched) {
     const int64_t Mp = pn_pad(M);
+    if (M_batched < 2 * Mp) M_batched = 2 * Mp;
     int64_t n = 0;
     n += 9 * Mp * PN_WIDTH;       // delta_0..delta_7 (kept: the weight-gradient stream reads them) + head addend
     n += 8 * Mp * PN_WIDTH;       // tangent hdot_0..hdot_7
     n += Mp * PN_WIDTH;           // d_bott
+    n += Mp * PN_ENC_DIM;         // edot            (up to here: carve_keep)
     n += Mp * PN_WIDTH_COND;      // d view hidden
-    n += 2 * Mp * PN_ENC_DIM;     // edot, d_enc
+    n += Mp * PN_ENC_DIM;         // d_enc
     n += Mp * 32;                 // expanded viewenc
     n += Mp * 8 + Mp * 2;         // dden copy, sdot, coef
-    n += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);  // slabs
+    n += slab_floats(M_batched + 4 * PN_ROW_PAD);  // slabs
     n += 9 * (Mp / 64) * PN_WIDTH + 64 * 9 * PN_WIDTH + 9 * PN_WIDTH;  // epilogue column sums + reduce scratch
     int64_t nb = (M + HEAD_ROWS - 1) / HEAD_ROWS;
     int64_t hp = nb * (5 * PN_WIDTH + 5) + 64 * (5 * PN_WIDTH + 5);
@@ -573,8 +616,14 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
                     const float* wpack, const float* mean, const float* cov, const float* enc, const float* viewenc,
                     const float* acts, const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
                     const float* d_raw_density, const float* rsweep, const float* v_gradmean, float* d_mean,
-                    float* grads, float* work, void* stream, void* side_stream) {
+                    float* grads, float* work, int64_t M_batched, int defer_wgrad, int n_deferred,
+                    const int64_t* dM_host, const float* const* denc_host, const float* const* dacts_host,
+                    const float* const* drsweep_host, float* const* dwork_host, const int* dtangent_host, void* stream,
+                    void* side_stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
+    if (n_deferred < 0 || n_deferred > 2 || (defer_wgrad && n_deferred)) return PN_ERR_BAD_SHAPE;
+    if (n_deferred && (!dM_host || !denc_host || !dacts_host || !drsweep_host || !dwork_host || !dtangent_host))
+        return PN_ERR_NULL;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     if (!params || !wpack || !mean || !cov || !enc || !viewenc || !acts || !masks || !raw_density || !d_raw_rgb ||
         !d_raw_density || !grads || !work)
@@ -599,20 +648,21 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     auto rs = [&](int i) { return rsweep + (int64_t)i * Mp * PN_WIDTH; };
     auto mask = [&](int i) { return masks + (int64_t)i * Mp * PN_MASK_WORDS; };
     // carve the workspace (every piece is a multiple of 4 floats -> 16-B aligned if `work` is)
-    float* w = work;
-    float* dbuf = w; w += 9 * Mp * PN_WIDTH;
-    auto delta = [&](int l) { return dbuf + (int64_t)l * Mp * PN_WIDTH; };  // l = 0..7; 8 = head addend
-    float* tbuf = w; w += 8 * Mp * PN_WIDTH;
-    auto tang = [&](int l) { return tbuf + (int64_t)l * Mp * PN_WIDTH; };
-    float* dbott = w; w += Mp * PN_WIDTH;
+    float* w = nullptr;
+    const BwdKeep keep = carve_keep(work, Mp, &w);
+    auto delta = [&](int l) { return keep.delta(l); };
+    auto tang = [&](int l) { return keep.tang(l); };
+    float* dbott = keep.dbott;
+    float* edot = keep.edot;
     float* dvh = w; w += Mp * PN_WIDTH_COND;
-    float* edot = w; w += Mp * PN_ENC_DIM;
     float* denc = w; w += Mp * PN_ENC_DIM;
     float* VE = w; w += Mp * 32;
     float* dden = w; w += Mp * 8;
     float* sdot = w; w += Mp;
     float* coef = w; w += Mp;
-    float* slab = w; w += pn_tn_work_floats(2 * Mp, PN_WIDTH, PN_WIDTH);
+    if (M_batched < 2 * Mp) M_batched = 2 * Mp;
+    const int64_t slab_avail = slab_floats(M_batched + 4 * PN_ROW_PAD);
+    float* slab = w; w += slab_avail;
     float* csum = w; w += 9 * (Mp / 64) * PN_WIDTH;   // [9 biases][row partials][256] from the GEMM epilogues
     float* csum_scratch = w; w += 64 * 9 * PN_WIDTH + 9 * PN_WIDTH;
     float* partial = w;
@@ -620,6 +670,56 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     auto csum_slot = [&](int slot) { return csum + (int64_t)slot * csum_rows * PN_WIDTH; };
     const int ld5 = PN_WIDTH + PN_ENC_DIM;
     const int ldv = PN_WIDTH + PN_VIEW_DIM;
+    // Weight gradients of the trunk and the extra layer: either deferred (operands stay in `work` for a later call)
+    // or computed here over the rows of THIS evaluation plus the deferred ones — one TN GEMM per layer over up to
+    // four row segments (own, env, level-1 first-order, level-1 tangent) instead of one per evaluation.
+    BwdKeep dk[2];
+    int64_t dMp[2] = {0, 0};
+    for (int e = 0; e < n_deferred; ++e) {
+        if (dM_host[e] <= 0 || !denc_host[e] || !dacts_host[e] || !dwork_host[e]) return PN_ERR_NULL;
+        if (dtangent_host[e] && !drsweep_host[e]) return PN_ERR_NULL;
+        dMp[e] = pn_pad(dM_host[e]);
+        dk[e] = carve_keep(dwork_host[e], dMp[e], nullptr);
+    }
+    // layer l in 0..7: dW_l (+ skip columns for l == 5); l == 8: extra layer
+    auto trunk_wgrad = [&](int l, bool own_first_order, bool own_tangent) -> int {
+        if (defer_wgrad) return PN_OK;
+        const int nparts = (l == 5) ? 2 : 1;
+        for (int part = 0; part < nparts; ++part) {
+            PnSegTn segs[4];
+            int ns = 0;
+            bool overflow = false;
+            const bool skip = part == 1;                 // layer 5, columns 256..351 (against enc / edot)
+            const bool from_enc = skip || l == 0;
+            const int ldy = from_enc ? PN_ENC_DIM : PN_WIDTH;
+            auto add = [&](const float* X, const float* Y, int64_t rows) {
+                if (ns < 4) segs[ns++] = PnSegTn{X, Y, PN_WIDTH, ldy, rows};
+                else overflow = true;
+            };
+            auto acts_of = [&](const float* a, int64_t mp, int i) { return a + (int64_t)i * mp * PN_WIDTH; };
+            if (l == 8) {
+                if (own_first_order) add(dbott, act(7), M);
+                for (int e = 0; e < n_deferred; ++e) add(dk[e].dbott, acts_of(dacts_host[e], dMp[e], 7), dM_host[e]);
+            } else {
+                if (own_first_order) add(delta(l), from_enc ? enc : act(l - 1), M);
+                if (own_tangent) add(rs(l), from_enc ? edot : tang(l - 1), M);
+                for (int e = 0; e < n_deferred; ++e) {
+                    add(dk[e].delta(l), from_enc ? denc_host[e] : acts_of(dacts_host[e], dMp[e], l - 1), dM_host[e]);
+                    if (dtangent_host[e])
+                        add(drsweep_host[e] + (int64_t)l * dMp[e] * PN_WIDTH, from_enc ? dk[e].edot : dk[e].tang(l - 1),
+                            dM_host[e]);
+                }
+            }
+            if (overflow) return PN_ERR_UNSUPPORTED;  // more than four row segments
+            if (ns == 0) continue;
+            float* dst = (l == 8) ? grads + L.we : grads + L.w[l] + (skip ? PN_WIDTH : 0);
+            const int n2 = from_enc ? PN_ENC_DIM : PN_WIDTH;
+            const int ldw = (l == 8) ? PN_WIDTH : (l == 0 ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH));
+            RUN(pn_launch_gemm_tn(segs, ns, PN_WIDTH, n2, dst, ldw, 1, slab, slab_avail, ws));
+        }
+        return PN_OK;
+    };
+    const bool inline_tangent = v_gradmean && !defer_wgrad && n_deferred == 0;  // stand-alone call: as before
 
     {
         const PnLayout L_ = pn_layout(nc);
@@ -640,11 +740,8 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         const float* prev = edot;
         int prev_ld = PN_ENC_DIM;
         for (int l = 0; l < 8; ++l) {
-            // dW_l += r_l^T * hdot_{l-1}   (layer 5 also against edot for the skip columns)
-            int kin = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
-            int ldw = (l == 0) ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH);
-            RUN(wgrad(M, rs(l), PN_WIDTH, PN_WIDTH, prev, prev_ld, kin, grads + L.w[l], ldw, slab, ws));
-            if (l == 5) RUN(wgrad(M, rs(5), PN_WIDTH, PN_WIDTH, edot, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, ws));
+            // dW_l += r_l^T * hdot_{l-1}: stand-alone calls do it here, otherwise it rides in the batched trunk GEMMs
+            if (inline_tangent) RUN(trunk_wgrad(l, false, true));
             // hdot_l = gate_l * (hdot_{l-1} * W_l^T)
             float* cur = tang(l);
             PnGemmNt g;
@@ -676,7 +773,7 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     // ---------------- colour head + view layer ------------------------------------------------
     RUN((head_bwd_data<2, 3>(M, d_raw_rgb, 3, params + L.wc, dvh, PN_WIDTH_COND, act(9), PN_WIDTH, s)));
     RUN(hand_off());
-    RUN(wgrad(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, act(8), PN_WIDTH, PN_WIDTH, grads + L.wv, ldv, slab, ws));
+    RUN(wgrad(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, act(8), PN_WIDTH, PN_WIDTH, grads + L.wv, ldv, slab, slab_avail, ws));
     hipLaunchKernelGGL(k_expand_viewenc, dim3(nblk(M * 32, 256)), dim3(256), 0, ws, M, rows_per_ray, view_rows, viewenc,
                        VE);
     PN_CHECK_LAUNCH();
@@ -684,7 +781,7 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
         PnSegTn sg{dvh, VE, PN_WIDTH_COND, 32, M};
         // [128][32] product; only the first 27 columns exist in the parameter: land it in scratch, then add
         float* tmp = partial;  // 128*32 floats
-        RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, tmp, 32, 0, slab, ws));
+        RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, tmp, 32, 0, slab, slab_avail, ws));
         RUN(pn_launch_reduce_rows(tmp, 1, 0, PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv, 1, nullptr, ws));
     }
     RUN(colsum_into(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv, partial, ws));
@@ -698,7 +795,7 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     if (nc == 5) RUN((head_bwd_data<4, 5>(M, dden_use, 5, params + L.wd, delta(8), PN_WIDTH, nullptr, 0, s)));
     else RUN((head_bwd_data<4, 1>(M, dden_use, 1, params + L.wd, delta(8), PN_WIDTH, nullptr, 0, s)));
     RUN(hand_off());
-    RUN(wgrad(M, dbott, PN_WIDTH, PN_WIDTH, act(7), PN_WIDTH, PN_WIDTH, grads + L.we, PN_WIDTH, slab, ws));
+    RUN(trunk_wgrad(8, true, false));
     if (nc == 5) RUN((head_bwd_weight<4, 5>(M, dden_use, 5, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, ws)));
     else RUN((head_bwd_weight<4, 1>(M, dden_use, 1, nullptr, act(7), PN_WIDTH, grads + L.wd, grads + L.bd, partial, ws)));
     {  // delta_7 = gate_7 * (d_bott * We + d_raw_density * Wd)
@@ -713,12 +810,7 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     // ---------------- trunk ---------------------------------------------------------------------
     for (int l = 7; l >= 0; --l) {
         RUN(hand_off());  // delta_l is complete on the main stream
-        const float* xin = (l == 0) ? enc : act(l - 1);
-        int ldx = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
-        int kin = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
-        int ldw = (l == 0) ? PN_ENC_DIM : (l == 5 ? ld5 : PN_WIDTH);
-        RUN(wgrad(M, delta(l), PN_WIDTH, PN_WIDTH, xin, ldx, kin, grads + L.w[l], ldw, slab, ws));
-        if (l == 5) RUN(wgrad(M, delta(5), PN_WIDTH, PN_WIDTH, enc, PN_ENC_DIM, PN_ENC_DIM, grads + L.w[5] + PN_WIDTH, ld5, slab, ws));
+        RUN(trunk_wgrad(l, true, v_gradmean && !inline_tangent));
         if (l > 0) {
             PnGemmNt g = nt(M, PN_WIDTH, delta(l), PN_WIDTH, wpack + P.wt[l], PN_WIDTH, PN_WIDTH, delta(l - 1), PN_WIDTH);
             g.gate_bits = mask(l - 1);
@@ -766,7 +858,7 @@ int64_t pn_gemm_tn_work_floats(int64_t M, int N1, int N2) { return pn_tn_work_fl
 int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* Y, int ldy, float* C, int ldc,
                int accumulate, float* work, void* stream) {
     PnSegTn sg{X, Y, ldx, ldy, M};
-    return pn_launch_gemm_tn(&sg, 1, N1, N2, C, ldc, accumulate, work, ST(stream));
+    return pn_launch_gemm_tn(&sg, 1, N1, N2, C, ldc, accumulate, work, -1, ST(stream));
 }
 
 const char* pn_strerror(int code) {

@@ -85,14 +85,31 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
-def _mlp_backward(ev, cfg, params, wpack, d_raw_rgb, d_raw_den, v, d_mean, flat_grad, st):
-    n = int(_lib.load().pn_mlp_backward_work_floats(ev.M, ev.view_rows))
+def _mlp_backward(ev, cfg, params, wpack, d_raw_rgb, d_raw_den, v, d_mean, flat_grad, st, defer=False, deferred=()):
+    """One evaluation's backward.  `defer=True` leaves its trunk weight-gradient operands in the returned workspace;
+    the last call of the step passes those as `deferred` = [(eval, work, had_tangent), ...] and reduces them all in
+    one GEMM per layer."""
+    import ctypes
+    m_batched = ev.M * (2 if v is not None else 1) + sum(e.M * (2 if t else 1) for e, _, t in deferred)
+    n = int(_lib.load().pn_mlp_backward_work_floats(ev.M, ev.view_rows, m_batched if deferred else 0))
     work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
+    nd = len(deferred)
+    if nd:
+        dM = (ctypes.c_int64 * nd)(*[e.M for e, _, _ in deferred])
+        denc = (ctypes.c_void_p * nd)(*[e.enc.data_ptr() for e, _, _ in deferred])
+        dacts = (ctypes.c_void_p * nd)(*[e.acts.data_ptr() for e, _, _ in deferred])
+        drs = (ctypes.c_void_p * nd)(*[(e.rsweep.data_ptr() if t else None) for e, _, t in deferred])
+        dwork = (ctypes.c_void_p * nd)(*[w.data_ptr() for _, w, _ in deferred])
+        dtan = (ctypes.c_int * nd)(*[int(bool(t)) for _, _, t in deferred])
+    else:
+        dM = denc = dacts = drs = dwork = dtan = None
     _lib.call("pn_mlp_backward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, cfg.density_bias, params.data_ptr(),
               wpack.data_ptr(), ev.mean.data_ptr(), ev.cov.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
               ev.acts.data_ptr(), ev.masks.data_ptr(), ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(),
-              _lib.ptr(ev.rsweep), _lib.ptr(v), _lib.ptr(d_mean), flat_grad.data_ptr(), work.data_ptr(), st,
+              _lib.ptr(ev.rsweep), _lib.ptr(v), _lib.ptr(d_mean), flat_grad.data_ptr(), work.data_ptr(),
+              m_batched if deferred else 0, int(defer), nd, dM, denc, dacts, drs, dwork, dtan, st,
               _side_stream(flat_grad.device).cuda_stream if cfg.overlap else None)
+    return work
 
 
 class _RenderFn(torch.autograd.Function):
@@ -186,6 +203,7 @@ class _RenderFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             flat_grad = z(params.numel())
+            pending = []  # (evaluation, its workspace, ran the tangent sweep): weight gradients batched into the last call
             d_dist1 = gz(g_dist1, B).clone()
             d_normal = gz(g_normal, B, 3) if cfg.normals else None
             d_albedo = None
@@ -202,7 +220,8 @@ class _RenderFn(torch.autograd.Function):
                 d_rr, d_rd = z(ee.M, 3), z(ee.M, nc)
                 _composite_backward(ee, B * D, Ne, cfg, False, env_d, D, d_env, None, None, d_rr, d_rd, st)
                 d_mean_e = z(ee.M, 3)
-                _mlp_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, flat_grad, st)
+                pending.append((ee, _mlp_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, flat_grad, st,
+                                                  defer=cfg.batch_wgrad), False))
                 _lib.call("pn_env_origin_backward", B, D * Ne, d_mean_e.data_ptr(), d.data_ptr(), d_dist1.data_ptr(), st)
             d_rr, d_rd = z(M, 3), z(M, nc)
             d_w1 = v = None
@@ -215,11 +234,15 @@ class _RenderFn(torch.autograd.Function):
                           e1.raw_den.data_ptr(), d.data_ptr(), d_normal.data_ptr(), _lib.ptr(d_ort_ray),
                           _lib.ptr(d_albedo), d_w1.data_ptr(), v.data_ptr(), d_rd.data_ptr(), st)
             _composite_backward(e1, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp1, B, 3), d_dist1, d_w1, d_rr, d_rd, st)
-            _mlp_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, flat_grad, st)
+            pending.append((e1, _mlp_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, flat_grad, st,
+                                              defer=cfg.batch_wgrad), v is not None))
+            if not cfg.batch_wgrad:
+                pending = []
             d_rr0, d_rd0 = z(M, 3), z(M, nc)
             _composite_backward(e0, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp0, B, 3), gz(g_dist0, B), None, d_rr0,
                                 d_rd0, st)
-            _mlp_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, flat_grad, st)
+            _mlp_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, flat_grad, st, deferred=pending)
+            pending = []
         mlp.last_flat_grad = flat_grad
         ctx.pack = None
         return (None,) * 16 + tuple(mlp.grad_views(flat_grad))
@@ -272,6 +295,7 @@ class _RenderBase(torch.nn.Module):
             raise NotImplementedError(f"{type(self).__name__} needs mlp_num_density_channels={self._NC}")
         self.noise_override = None  # tests: dict(t_rand=[B,S], u_rand=[B,S], env_rand=[1,Ne+1])
         self.overlap_weight_grads = True  # weight-gradient GEMMs on a side stream (same results, different order of launch)
+        self.batch_weight_grads = True    # one weight-gradient GEMM per layer over env + level-1 + level-0 rows
 
     def _noise(self, randomized, B, dev, want_env):
         if not randomized:
@@ -302,6 +326,7 @@ class _RenderBase(torch.nn.Module):
                    rgb_padding=self.rgb_padding, resample_padding=self.resample_padding,
                    white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
                    num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads,
+                   batch_wgrad=self.batch_weight_grads,
                    keep=torch.is_grad_enabled() and any(p.requires_grad for p in self.mlp.parameters()))
         plist = [p for _, p in self.mlp.named_in_order()]
         outs = _RenderFn.apply(cfg, self.mlp, o, d, vd, radii, near, far, *env, t_rand, u_rand,

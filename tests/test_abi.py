@@ -65,6 +65,20 @@ def test_library_exports_every_symbol():
     assert handle.pn_strerror(-2).decode().startswith("unsupported")
 
 
+def test_split_k_workspace_is_monotone_in_rows():
+    """A batched weight-gradient GEMM runs over FEWER rows than its workspace was sized for (the segments of one
+    layer vary); the split-K slab count must therefore never shrink as rows grow (host arithmetic only, no launch)."""
+    handle = importlib.import_module("pano_nerf_amd._lib").load()
+    for n1, n2 in ((256, 256), (256, 96), (128, 256), (128, 32)):
+        prev = 0
+        for rows in list(range(1, 4000, 37)) + list(range(4000, 700000, 4099)):
+            cur = handle.pn_gemm_tn_work_floats(rows, n1, n2)
+            assert cur >= prev and cur % (n1 * n2) == 0, (rows, n1, n2)
+            prev = cur
+    # the workspace of one backward call covers its batched row count and every smaller one
+    assert handle.pn_mlp_backward_work_floats(8481, 257, 51143) >= handle.pn_mlp_backward_work_floats(8481, 257, 42662)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     lib = importlib.import_module("pano_nerf_amd._lib")
     monkeypatch.setattr(lib, "_lib", None)
