@@ -101,11 +101,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     import torch.distributed as dist
+    # PN_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (ranks then
+    # share devices round-robin and the gradient all-reduce goes through the host); never used for reported numbers
+    backend = os.environ.get("PN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import pano_nerf_amd as pn
     from pano_nerf_amd import _lib
@@ -148,7 +156,9 @@ def main():
     graph = None
     state = {}
 
-    def step(i):
+    def step(i, local=False):
+        """One training step.  `local=True` (rank-0-only measurement legs after the timed region) skips the gradient
+        all-reduce: a collective issued by one rank alone would never complete."""
         lr_dev.fill_(pn.mip_lr(i))
         if graph is not None:
             graph.replay()
@@ -157,9 +167,9 @@ def main():
                 return loss, pred, gt  # Adam is part of the graph
         else:
             loss, pred, gt, g = fwd_bwd()
-        if world > 1:
+        if world > 1 and not local:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        opt.step_dev(g, lr_dev, grad_scale=1.0 / world)
+        opt.step_dev(g, lr_dev, grad_scale=1.0 if local else 1.0 / world)
         return loss, pred, gt
 
     def try_capture():
@@ -236,11 +246,11 @@ def main():
     iso = {}
     if rank == 0:
         model.overlap_weight_grads = False
-        step(args.warmup + args.steps)
+        step(args.warmup + args.steps, local=True)
         torch.cuda.synchronize()
         _lib.load().pn_prof_enable(1)
         for i in range(2):
-            step(args.warmup + args.steps + 1 + i)
+            step(args.warmup + args.steps + 1 + i, local=True)
         torch.cuda.synchronize()
         for cls, name in ((0, "k_gemm_nt"), (1, "k_gemm_tn")):
             ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
@@ -288,7 +298,9 @@ def main():
                                      "replayed graph; same kernels, same shapes)"),
                          "note": "timed region runs the weight-gradient GEMMs (k_gemm_tn) on a side stream, concurrently "
                                  "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the same "
-                                 "kernels in 2 extra steps with the side stream off",
+                                 "kernels in 2 extra steps with the side stream off.  `peak` is the 2.4 GHz datasheet figure; under "
+                                 "the power cap the same k_gemm_nt binary runs 126 TF on zero/constant operands and 101 TF on "
+                                 "N(0,1) operands (tools/bench_clock.py, profiles/r01_clock_vs_data.txt)",
                          "isolated": iso,
                          "flop_per_launch": fl / max(n, 1),
                          "other": {k: {"total_ms": v[0], "launches": v[1],

@@ -1241,6 +1241,33 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* src, int64_t n
     }
 }
 
+// Split-K slabs [nb][n] (contiguous, n % 4 == 0): first stage of their reduction, in place.  Block (x, y) sums the
+// slabs of its range [y*per, (y+1)*per) over the 256 floats x owns and writes the result over the FIRST slab of its
+// range (only this block touches that region), float4 per lane, 4 partial lanes per element, fixed order.
+__global__ __launch_bounds__(256) void k_reduce_slabs4(float* slab, int64_t nb, int64_t stride4, int n4, int64_t per) {
+    __shared__ f32x4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    const int64_t b0 = (int64_t)blockIdx.y * per;
+    int64_t b1 = b0 + per;
+    if (b1 > nb) b1 = nb;
+    if (b0 >= nb) return;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0 = z, a1 = z, a2 = z, a3 = z;
+    f32x4* p = reinterpret_cast<f32x4*>(slab) + (e < n4 ? e : 0);
+    int64_t b = b0 + ty;
+    for (; b + 12 < b1; b += 16) {
+        a0 += p[b * stride4];
+        a1 += p[(b + 4) * stride4];
+        a2 += p[(b + 8) * stride4];
+        a3 += p[(b + 12) * stride4];
+    }
+    for (; b < b1; b += 4) a0 += p[b * stride4];
+    red[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && e < n4) p[b0 * stride4] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
 int pn_launch_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols, int src_ld, float* dst,
                           int ldd, int accumulate, float* scratch, hipStream_t s) {
     const int n = rows * cols;
@@ -1329,5 +1356,18 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
         } else hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
     }
     PN_CHECK_LAUNCH();
-    return pn_launch_reduce_rows(work, nsplit, (int64_t)N1 * N2, N1, N2, N2, C, ldc, accumulate, nullptr, s);
+    const int64_t n = (int64_t)N1 * N2;
+    if (nsplit >= 32) {  // two stages: Y in-place partial sums (float4 streams), then the final accumulate into C
+        const int n4 = (int)(n / 4);
+        const int bx = (n4 + 63) / 64;
+        int64_t Y = (1024 + bx - 1) / bx;          // ~4096 waves in flight
+        if (Y > nsplit / 8) Y = nsplit / 8;
+        if (Y < 1) Y = 1;
+        const int64_t per = (nsplit + Y - 1) / Y;
+        Y = (nsplit + per - 1) / per;
+        hipLaunchKernelGGL(k_reduce_slabs4, dim3(bx, (unsigned)Y), dim3(256), 0, s, work, (int64_t)nsplit, n / 4, n4, per);
+        PN_CHECK_LAUNCH();
+        return pn_launch_reduce_rows(work, Y, per * n, N1, N2, N2, C, ldc, accumulate, nullptr, s);
+    }
+    return pn_launch_reduce_rows(work, nsplit, n, N1, N2, N2, C, ldc, accumulate, nullptr, s);
 }

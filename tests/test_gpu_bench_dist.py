@@ -1,0 +1,31 @@
+"""Two-rank rehearsal of bench.py's control flow on ONE GPU (gloo collectives through the host, both ranks on cuda:0):
+the launch contract (torch.distributed.run, env rendezvous), rank-0-only measurement legs that must not issue
+collectives, and the single JSON line.  The reported numbers of a real multi-GPU run use RCCL; this only proves the
+flow terminates and the line is well-formed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("graph", ["off", "on"])
+def test_two_rank_bench_flow(graph):
+    env = dict(os.environ, PN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--global-batch", "256", "--samples", "32", "--height", "64", "--width", "128", "--graph",
+           graph]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["rays_per_gpu"] == 128 and out["value"] > 0
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
