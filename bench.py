@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
+    ap.add_argument("--overlap", choices=("on", "off"), default="off",
+                    help="weight-gradient GEMMs on a side stream (on) or in line on the main stream (off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,6 +138,7 @@ def main():
 
     model = pn.PanoMipNeRF(num_samples=args.samples, rgb_activation="softplus", rgb_padding=0,
                            mlp_num_density_channels=5, num_env_samples=10).to(dev)
+    model.overlap_weight_grads = args.overlap == "on"
     if world > 1:  # identical replicas
         dist.broadcast(model.mlp.flat_params(), 0)
     opt = pn.FlatAdam(model.mlp, lr=2e-4)
@@ -244,7 +247,7 @@ def main():
         graph = None
     # the same kernels with the side stream off: per-launch durations without time-sharing (not part of `value`)
     iso = {}
-    if rank == 0:
+    if rank == 0 and args.overlap == "on":
         model.overlap_weight_grads = False
         step(args.warmup + args.steps, local=True)
         torch.cuda.synchronize()
@@ -258,7 +261,7 @@ def main():
             iso[name] = {"avg_launch_us": 1e3 * ms.value / max(n.value, 1), "tflops": fl.value / max(ms.value, 1e-9) / 1e9,
                          "frac": fl.value / max(ms.value, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS}
         _lib.load().pn_prof_enable(0)
-        model.overlap_weight_grads = True
+        model.overlap_weight_grads = args.overlap == "on"
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -296,11 +299,13 @@ def main():
                          "measured": "HIP events around every GEMM launch " + ("during the timed region" if prof_live else
                                      "on 2 eager steps right after the timed region (events cannot be recorded inside a "
                                      "replayed graph; same kernels, same shapes)"),
-                         "note": "timed region runs the weight-gradient GEMMs (k_gemm_tn) on a side stream, concurrently "
-                                 "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the same "
-                                 "kernels in 2 extra steps with the side stream off.  `peak` is the 2.4 GHz datasheet figure; under "
-                                 "the power cap the same k_gemm_nt binary runs 126 TF on zero/constant operands and 101 TF on "
-                                 "N(0,1) operands (tools/bench_clock.py, profiles/r01_clock_vs_data.txt)",
+                         "note": ("timed region runs the weight-gradient GEMMs (k_gemm_tn) on a side stream, concurrently "
+                                  "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the "
+                                  "same kernels in 2 extra steps with the side stream off.  " if args.overlap == "on" else
+                                  "all launches on one stream (no time sharing between kernels).  ") +
+                                 "`peak` is the 2.4 GHz datasheet figure; under the power cap the same k_gemm_nt binary runs "
+                                 "126 TF on zero/constant operands and 101 TF on N(0,1) operands (tools/bench_clock.py, "
+                                 "profiles/r01_clock_vs_data.txt)",
                          "isolated": iso,
                          "flop_per_launch": fl / max(n, 1),
                          "other": {k: {"total_ms": v[0], "launches": v[1],

@@ -132,7 +132,9 @@ int pn_density_grad(int64_t M, int num_density_channels, float density_bias, con
  *     path: needs rsweep from pn_density_grad; d_raw_density[:,0] receives the
  *     softplus'' term internally);
  *   d_mean [M,3] or null: if non-null receives d loss / d mean (first-order, env-light path).
- * work: scratch of pn_mlp_backward_work_floats(M, view_rows) floats.
+ * M is a whole number of rays (M % rows_per_ray == 0) and the rays cycle through the view rows
+ * ((M / rows_per_ray) % view_rows == 0): ray r uses viewenc[r % view_rows], as in pn_mlp_forward.
+ * work: scratch of pn_mlp_backward_work_floats(M, rows_per_ray, view_rows, M_batched) floats.
  * Batching the weight gradients of one training step: the evaluations of a step (env light, level 1, level 0) share
  * the weights, so their trunk / extra-layer weight gradients are ONE TN GEMM per layer over all their rows.  Calls with
  * defer_wgrad = 1 skip those GEMMs and leave their operands in `work` (keep it alive); the last call passes
@@ -141,7 +143,7 @@ int pn_density_grad(int64_t M, int num_density_channels, float density_bias, con
  * rows counted) sizes the slab part of `work` (0 = stand-alone).
  * side_stream (nullable): a second hipStream_t; when given, the weight-gradient GEMMs / reductions run there,
  * forked from and joined back to `stream` with events inside the call, so they overlap the data-gradient chain. */
-int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows, int64_t M_batched);
+int64_t pn_mlp_backward_work_floats(int64_t M, int rows_per_ray, int64_t view_rows, int64_t M_batched);
 int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, float density_bias,
                     const float* params, const float* wpack, const float* mean, const float* cov,
                     const float* enc, const float* viewenc, const float* acts, const uint32_t* masks,

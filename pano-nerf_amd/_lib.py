@@ -30,7 +30,7 @@ SIGNATURES = {
     "pn_pos_enc_view": ("i", "lppp"),
     "pn_mlp_forward": ("i", "lili" + "p" * 12 + "p"),
     "pn_density_grad": ("i", "lif" + "p" * 10 + "p"),
-    "pn_mlp_backward_work_floats": ("l", "lll"),
+    "pn_mlp_backward_work_floats": ("l", "lill"),
     "pn_mlp_backward": ("i", "lilif" + "p" * 16 + "lii" + "p" * 6 + "pp"),
     "pn_composite_forward": ("i", "liiffi" + "pppp" + "l" + "pppp" + "p"),
     "pn_composite_backward": ("i", "liiffi" + "pppp" + "l" + "ppppp" + "p"),

@@ -122,136 +122,248 @@ static int transpose_into(const float* src, int ld, int c0, int rows, int cols, 
     return PN_OK;
 }
 
-// -------------------------------------------------------------------------- narrow heads (VALU)
-// out[row,c] = b[c] + sum_k x[row,k] * W[c,k]      K = 64*VEC, one wavefront per row (grid-stride)
-template <int VEC, int NC>
+// -------------------------------------------------------------------------- narrow heads (VALU, HBM-bound)
+// Rows are [K] floats, K = 128 or 256.  A wave covers FOUR rows at a time: 16 lanes per row, each lane owning
+// J = K/64 float4 (columns (16j + q)*4 .. +3, q = lane & 15), so every load/store instruction moves four full
+// 256-B row segments, a row reduction is four DPP rotations inside the 16-lane row, and the NC x K weights are
+// read as LDS broadcasts.  (One wave per row needed 6 cross-lane steps per output and ran at 1.7 TB/s.)
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row; every lane gets it
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
+    return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+}
+#define HEAD_U 2  // row quads in flight per wave iteration
+
+// out[row,c] = b[c] + sum_k x[row,k] * W[c,k]
+template <int K, int NC>
 __global__ __launch_bounds__(256) void k_head_fwd(int64_t M, const float* x, int ldx, const float* W, const float* b,
                                                    float* out, int ldo) {
-    const int lane = threadIdx.x & 63;
+    constexpr int J = K / 64;
+    __shared__ __attribute__((aligned(16))) float Ws[NC * K];
+    for (int i = threadIdx.x; i < NC * K; i += 256) Ws[i] = W[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = lane & 15;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    float w[NC][VEC];
+    const float bq = (b && q < NC) ? b[q] : 0.f;
+    for (int64_t row0 = wave * (4 * HEAD_U); row0 < M; row0 += nwaves * (4 * HEAD_U)) {
+        f32x4 xv[HEAD_U][J];
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+        for (int u = 0; u < HEAD_U; ++u) {
+            int64_t row = row0 + 4 * u + g;
+            row = row < M ? row : M - 1;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) w[c][v] = W[c * (64 * VEC) + lane * VEC + v];
-    // 4 rows per iteration: four independent 1-KB row loads in flight per wave (the kernel is HBM-latency bound)
-    for (int64_t row0 = wave * 4; row0 < M; row0 += nwaves * 4) {
-        float xv[4][VEC];
+            for (int j = 0; j < J; ++j) xv[u][j] = *reinterpret_cast<const f32x4*>(x + row * ldx + (16 * j + q) * 4);
+        }
+        float s[HEAD_U][NC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = row0 + u < M ? row0 + u : M - 1;
+        for (int c = 0; c < NC; ++c) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) xv[u][v] = x[row * ldx + lane * VEC + v];
+            for (int u = 0; u < HEAD_U; ++u) s[u][c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(Ws + c * K + (16 * j + q) * 4);
+#pragma unroll
+                for (int u = 0; u < HEAD_U; ++u) s[u][c] += dot4(xv[u][j], w4);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = row0 + u;
+        for (int u = 0; u < HEAD_U; ++u) {
+            float mine = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                float s = 0.f;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) s += xv[u][v] * w[c][v];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (lane == 0 && row < M) out[row * ldo + c] = s + (b ? b[c] : 0.f);
+                const float t = row16_sum(s[u][c]);
+                mine = (q == c) ? t : mine;
             }
+            const int64_t row = row0 + 4 * u + g;
+            if (q < NC && row < M) out[row * ldo + q] = mine + bq;
         }
     }
 }
 
 // out[row,k] = sum_c d[row,c] * W[c,k]  (optionally gated by gate[row,k] > 0)
-template <int VEC, int NC>
+template <int K, int NC>
 __global__ __launch_bounds__(256) void k_head_bwd_data(int64_t M, const float* d, int ldd, const float* W, float* out,
                                                         int ldo, const float* gate, int ldg) {
-    const int lane = threadIdx.x & 63;
+    constexpr int J = K / 64;
+    __shared__ __attribute__((aligned(16))) float Ws[NC * K];
+    for (int i = threadIdx.x; i < NC * K; i += 256) Ws[i] = W[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = lane & 15;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    float w[NC][VEC];
+    for (int64_t row0 = wave * (4 * HEAD_U); row0 < M; row0 += nwaves * (4 * HEAD_U)) {
+        float dv[HEAD_U][NC];
+        f32x4 gt[HEAD_U][J];
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) w[c][v] = W[c * (64 * VEC) + lane * VEC + v];
-    for (int64_t row0 = wave * 4; row0 < M; row0 += nwaves * 4) {
-        float dv[4][NC];
-        float gt[4][VEC];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = row0 + u < M ? row0 + u : M - 1;
+        for (int u = 0; u < HEAD_U; ++u) {
+            int64_t row = row0 + 4 * u + g;
+            row = row < M ? row : M - 1;
 #pragma unroll
             for (int c = 0; c < NC; ++c) dv[u][c] = d[row * ldd + c];
+            if (gate) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) gt[u][v] = gate ? gate[row * ldg + lane * VEC + v] : 1.f;
+                for (int j = 0; j < J; ++j) gt[u][j] = *reinterpret_cast<const f32x4*>(gate + row * ldg + (16 * j + q) * 4);
+            }
+        }
+        f32x4 o[HEAD_U][J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+#pragma unroll
+            for (int u = 0; u < HEAD_U; ++u) o[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(Ws + c * K + (16 * j + q) * 4);
+#pragma unroll
+                for (int u = 0; u < HEAD_U; ++u) o[u][j] += dv[u][c] * w4;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = row0 + u;
-            if (row >= M) break;
+        for (int u = 0; u < HEAD_U; ++u) {
+            const int64_t row = row0 + 4 * u + g;
+            if (row >= M) continue;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                float s = 0.f;
+            for (int j = 0; j < J; ++j) {
+                f32x4 v = o[u][j];
+                if (gate) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) s += dv[u][c] * w[c][v];
-                if (!(gt[u][v] > 0.f)) s = 0.f;
-                out[row * ldo + lane * VEC + v] = s;
+                    for (int e = 0; e < 4; ++e) v[e] = gt[u][j][e] > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(out + row * ldo + (16 * j + q) * 4) = v;
             }
         }
     }
 }
 
 // partial[blk][c][k] = sum_{rows of blk} coef(row) * d[row,c] * x[row,k]; partial bias in [blk][NC*K + c]
-// coef(row) = coef ? coef[row] : 1
-template <int VEC, int NC>
+// coef(row) = coef ? coef[row] : 1.  16 row slots per block (4 waves x 4 row groups).
+template <int K, int NC>
 __global__ __launch_bounds__(256) void k_head_bwd_weight(int64_t M, int rows_per_block, const float* d, int ldd,
                                                           const float* coef, const float* x, int ldx, float* partial) {
-    constexpr int K = 64 * VEC;
-    __shared__ float red[4][NC * K + NC];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int J = K / 64;
+    __shared__ __attribute__((aligned(16))) float red[4][NC * K + NC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, q = lane & 15;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float acc[NC][VEC], bacc[NC];
+    f32x4 acc[NC][J];
+    float bacc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         bacc[c] = 0.f;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
+        for (int j = 0; j < J; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int64_t row = r0 + wv; row < r1; row += 4) {
-        float cf = coef ? coef[row] : 1.f;
-        float xv[VEC];
+    for (int64_t rb = r0 + wv * 4 + g; rb < r1; rb += 16 * HEAD_U) {
+        f32x4 xv[HEAD_U][J];
+        float dv[HEAD_U][NC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) xv[v] = x[row * ldx + lane * VEC + v];
+        for (int u = 0; u < HEAD_U; ++u) {
+            const int64_t row = rb + 16 * u;
+            const bool in = row < r1;
+            const int64_t rc = in ? row : r1 - 1;
+            const float cf = in ? (coef ? coef[rc] : 1.f) : 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float dv = d[row * ldd + c] * cf;
-            bacc[c] += dv;
+            for (int j = 0; j < J; ++j) xv[u][j] = *reinterpret_cast<const f32x4*>(x + rc * ldx + (16 * j + q) * 4);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[c][v] += dv * xv[v];
+            for (int c = 0; c < NC; ++c) dv[u][c] = d[rc * ldd + c] * cf;
         }
+#pragma unroll
+        for (int u = 0; u < HEAD_U; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                bacc[c] += dv[u][c];
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[c][j] += dv[u][c] * xv[u][j];
+            }
     }
+    // the four row groups of a wave, then the four waves
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) red[wv][c * K + lane * VEC + v] = acc[c][v];
-        if (lane == 0) red[wv][NC * K + c] = bacc[c];
+        for (int j = 0; j < J; ++j) {
+            f32x4 v = acc[c][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                v[e] = t;
+            }
+            if (g == 0) *reinterpret_cast<f32x4*>(&red[wv][c * K + (16 * j + q) * 4]) = v;
+        }
+        float t = bacc[c];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (lane == 0) red[wv][NC * K + c] = t;
     }
     __syncthreads();
     float* out = partial + (int64_t)blockIdx.x * (NC * K + NC);
-    for (int i = threadIdx.x; i < NC * K + NC; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    for (int i = threadIdx.x; i < NC * K + NC; i += 256) out[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-// column sums: partial[blk][col] = sum_{rows of blk} X[row, col]
-__global__ __launch_bounds__(256) void k_colsum(int64_t M, int rows_per_block, const float* X, int ldx, int N,
-                                                 float* partial) {
-    const int col = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+// S[ray][col] = sum over the rows_per_ray consecutive rows of a ray of X[row][col], K = 128 columns: feeds the
+// view-layer bias gradient (sum over rays) and its view-encoding weight gradient (the view encoding is constant
+// along a ray, so dWv[:, 256:] = sum_rays S[ray]^T viewenc[ray] needs no per-sample expansion).  One wave per ray.
+template <int K>
+__global__ __launch_bounds__(256) void k_ray_colsum(int64_t R, int rows_per_ray, const float* X, int ldx, float* S) {
+    constexpr int J = K / 64;
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = lane & 15;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t ray = wave; ray < R; ray += nwaves) {
+        const float* base = X + ray * rows_per_ray * (int64_t)ldx;
+        f32x4 acc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int r = g;
+        for (; r + 12 < rows_per_ray; r += 16) {
+            f32x4 t[4][J];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    t[u][j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(r + 4 * u) * ldx + (16 * j + q) * 4);
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[j] += (t[0][j] + t[1][j]) + (t[2][j] + t[3][j]);
+        }
+        for (; r < rows_per_ray; r += 4) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[j] += *reinterpret_cast<const f32x4*>(base + (int64_t)r * ldx + (16 * j + q) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            f32x4 v = acc[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                v[e] = t;
+            }
+            if (g == 0) *reinterpret_cast<f32x4*>(S + ray * K + (16 * j + q) * 4) = v;
+        }
+    }
+}
+
+// dWv[j][256 + i] += sum_v S2[v][j] * viewenc[v][i]   (j < 128, i < 27): block = one j, 8 partial lanes per i
+__global__ __launch_bounds__(256) void k_view_wgrad(int64_t V, const float* S2, const float* viewenc, float* dWv, int ldw) {
+    __shared__ float red[8][32];
+    const int j = blockIdx.x, i = threadIdx.x & 31, part = threadIdx.x >> 5;
     float s = 0.f;
-    if (col < N)
-        for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + col];
-    if (col < N) partial[(int64_t)blockIdx.x * N + col] = s;
+    if (i < PN_VIEW_DIM)
+        for (int64_t v = part; v < V; v += 8) s += S2[v * PN_WIDTH_COND + j] * viewenc[v * PN_VIEW_DIM + i];
+    red[part][i] = s;
+    __syncthreads();
+    if (part == 0 && i < PN_VIEW_DIM) {
+        float t = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
+        dWv[(int64_t)j * ldw + PN_WIDTH + i] += t;
+    }
 }
 
 struct BiasOffsets {
@@ -272,16 +384,6 @@ __global__ void k_view_bias(int64_t R, const float* viewenc, const float* Wv, co
     float s = 0.f;
     for (int i = 0; i < PN_VIEW_DIM; ++i) s += viewenc[r * PN_VIEW_DIM + i] * w[i];
     vb[idx] = s + bv[j];
-}
-
-// VE[row][i] = viewenc[(row / rows_per_ray) % view_rows][i], padded to 32 columns
-__global__ void k_expand_viewenc(int64_t M, int rows_per_ray, int64_t view_rows, const float* viewenc, float* VE) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * 32) return;
-    int64_t row = idx >> 5;
-    int i = (int)(idx & 31);
-    int64_t r = (row / rows_per_ray) % view_rows;
-    VE[idx] = (i < PN_VIEW_DIM) ? viewenc[r * PN_VIEW_DIM + i] : 0.f;
 }
 
 __device__ __forceinline__ float sp_d1(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
@@ -339,17 +441,25 @@ static void seg2(PnGemmNt& g, const float* A, int lda, const float* B, int ldb, 
     g.nseg = 2;
 }
 
+static unsigned head_grid(int64_t M) {  // 32 rows per block iteration, grid-stride, at most 8 blocks per CU
+    const int64_t nb = (M + 4 * 4 * HEAD_U - 1) / (4 * 4 * HEAD_U);
+    return (unsigned)(nb < 2048 ? (nb < 1 ? 1 : nb) : 2048);
+}
 template <int VEC, int NC>
 static int head_fwd(int64_t M, const float* x, int ldx, const float* W, const float* b, float* out, int ldo,
                     hipStream_t s) {
-    hipLaunchKernelGGL((k_head_fwd<VEC, NC>), dim3(2048), dim3(256), 0, s, M, x, ldx, W, b, out, ldo);
+    if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return PN_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL((k_head_fwd<64 * VEC, NC>), dim3(head_grid(M)), dim3(256), 0, s, M, x, ldx, W, b, out, ldo);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
 template <int VEC, int NC>
 static int head_bwd_data(int64_t M, const float* d, int ldd, const float* W, float* out, int ldo, const float* gate,
                          int ldg, hipStream_t s) {
-    hipLaunchKernelGGL((k_head_bwd_data<VEC, NC>), dim3(2048), dim3(256), 0, s, M, d, ldd, W, out, ldo, gate, ldg);
+    if ((ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15)) return PN_ERR_BAD_SHAPE;
+    if (gate && ((ldg & 3) || (reinterpret_cast<uintptr_t>(gate) & 15))) return PN_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL((k_head_bwd_data<64 * VEC, NC>), dim3(head_grid(M)), dim3(256), 0, s, M, d, ldd, W, out, ldo, gate,
+                       ldg);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
@@ -360,20 +470,14 @@ static int head_bwd_weight(int64_t M, const float* d, int ldd, const float* coef
                            float* db, float* partial, hipStream_t s) {
     constexpr int K = 64 * VEC;
     int nb = (int)nblk(M, HEAD_ROWS);
-    hipLaunchKernelGGL((k_head_bwd_weight<VEC, NC>), dim3(nb), dim3(256), 0, s, M, HEAD_ROWS, d, ldd, coef, x, ldx,
+    if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return PN_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL((k_head_bwd_weight<64 * VEC, NC>), dim3(nb), dim3(256), 0, s, M, HEAD_ROWS, d, ldd, coef, x, ldx,
                        partial);
     PN_CHECK_LAUNCH();
     float* scratch = partial + (int64_t)nb * (NC * K + NC);
     RUN(pn_launch_reduce_rows(partial, nb, NC * K + NC, NC, K, K, dW, K, 1, scratch, s));
     if (db) RUN(pn_launch_reduce_rows(partial + NC * K, nb, NC * K + NC, 1, NC, NC, db, NC, 1, scratch, s));
     return PN_OK;
-}
-#define COLSUM_ROWS 64
-static int colsum_into(int64_t M, const float* X, int ldx, int N, float* dst, float* partial, hipStream_t s) {
-    int nb = (int)nblk(M, COLSUM_ROWS);
-    hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, M, COLSUM_ROWS, X, ldx, N, partial);
-    PN_CHECK_LAUNCH();
-    return pn_launch_reduce_rows(partial, nb, N, 1, N, N, dst, N, 1, partial + (int64_t)nb * N, s);
 }
 static int wgrad(int64_t M, const float* X, int ldx, int N1, const float* Y, int ldy, int N2, float* dW, int ldw,
                  float* work, int64_t work_avail, hipStream_t s) {
@@ -590,7 +694,16 @@ static int64_t slab_floats(int64_t rows) {
     return n;
 }
 
-int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows, int64_t M_batched) {
+// per-ray sums of the view-layer gradient: S [R][128], folded S2 [view_rows][128], reduction scratch
+static int64_t view_sum_floats(int64_t M, int rows_per_ray, int64_t view_rows) {
+    const int64_t R = M / rows_per_ray;
+    int64_t n = R * PN_WIDTH_COND + view_rows * PN_WIDTH_COND + 64 * PN_WIDTH_COND;
+    if (R > view_rows && view_rows <= 1024) n += 64 * view_rows * PN_WIDTH_COND;
+    return (n + 3) & ~(int64_t)3;
+}
+
+int64_t pn_mlp_backward_work_floats(int64_t M, int rows_per_ray, int64_t view_rows, int64_t M_batched) {
+    if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0 || M % rows_per_ray) return PN_ERR_BAD_SHAPE;
     const int64_t Mp = pn_pad(M);
     if (M_batched < 2 * Mp) M_batched = 2 * Mp;
     int64_t n = 0;
@@ -600,15 +713,13 @@ int64_t pn_mlp_backward_work_floats(int64_t M, int64_t view_rows, int64_t M_batc
     n += Mp * PN_ENC_DIM;         // edot            (up to here: carve_keep)
     n += Mp * PN_WIDTH_COND;      // d view hidden
     n += Mp * PN_ENC_DIM;         // d_enc
-    n += Mp * 32;                 // expanded viewenc
+    n += view_sum_floats(M, rows_per_ray, view_rows);
     n += Mp * 8 + Mp * 2;         // dden copy, sdot, coef
     n += slab_floats(M_batched + 4 * PN_ROW_PAD);  // slabs
     n += 9 * (Mp / 64) * PN_WIDTH + 64 * 9 * PN_WIDTH + 9 * PN_WIDTH;  // epilogue column sums + reduce scratch
     int64_t nb = (M + HEAD_ROWS - 1) / HEAD_ROWS;
     int64_t hp = nb * (5 * PN_WIDTH + 5) + 64 * (5 * PN_WIDTH + 5);
-    int64_t cp = ((M + COLSUM_ROWS - 1) / COLSUM_ROWS) * PN_WIDTH + 64 * PN_WIDTH;
-    n += (hp > cp ? hp : cp) + 128 * 32 + 64;
-    (void)view_rows;
+    n += hp + 64;
     return n;
 }
 
@@ -621,6 +732,7 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
                     const float* const* drsweep_host, float* const* dwork_host, const int* dtangent_host, void* stream,
                     void* side_stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
+    if (M % rows_per_ray || (M / rows_per_ray) % view_rows) return PN_ERR_BAD_SHAPE;  // whole rays, cycling view rows
     if (n_deferred < 0 || n_deferred > 2 || (defer_wgrad && n_deferred)) return PN_ERR_BAD_SHAPE;
     if (n_deferred && (!dM_host || !denc_host || !dacts_host || !drsweep_host || !dwork_host || !dtangent_host))
         return PN_ERR_NULL;
@@ -656,7 +768,12 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     float* edot = keep.edot;
     float* dvh = w; w += Mp * PN_WIDTH_COND;
     float* denc = w; w += Mp * PN_ENC_DIM;
-    float* VE = w; w += Mp * 32;
+    const int64_t R = M / rows_per_ray;  // rays of this evaluation (view encoding is constant along a ray)
+    float* S = w;
+    float* S2buf = S + R * PN_WIDTH_COND;
+    float* bias_scratch = S2buf + view_rows * PN_WIDTH_COND;
+    float* fold_scratch = (R > view_rows && view_rows <= 1024) ? bias_scratch + 64 * PN_WIDTH_COND : nullptr;
+    w += view_sum_floats(M, rows_per_ray, view_rows);
     float* dden = w; w += Mp * 8;
     float* sdot = w; w += Mp;
     float* coef = w; w += Mp;
@@ -774,17 +891,22 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     RUN((head_bwd_data<2, 3>(M, d_raw_rgb, 3, params + L.wc, dvh, PN_WIDTH_COND, act(9), PN_WIDTH, s)));
     RUN(hand_off());
     RUN(wgrad(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, act(8), PN_WIDTH, PN_WIDTH, grads + L.wv, ldv, slab, slab_avail, ws));
-    hipLaunchKernelGGL(k_expand_viewenc, dim3(nblk(M * 32, 256)), dim3(256), 0, ws, M, rows_per_ray, view_rows, viewenc,
-                       VE);
-    PN_CHECK_LAUNCH();
-    {
-        PnSegTn sg{dvh, VE, PN_WIDTH_COND, 32, M};
-        // [128][32] product; only the first 27 columns exist in the parameter: land it in scratch, then add
-        float* tmp = partial;  // 128*32 floats
-        RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, tmp, 32, 0, slab, slab_avail, ws));
-        RUN(pn_launch_reduce_rows(tmp, 1, 0, PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv, 1, nullptr, ws));
+    {  // bias and view-encoding columns of the view layer from per-ray sums of dvh (no per-sample expansion)
+        unsigned gr = (unsigned)((R + 3) / 4);
+        if (gr > 2048) gr = 2048;
+        hipLaunchKernelGGL((k_ray_colsum<PN_WIDTH_COND>), dim3(gr), dim3(256), 0, ws, R, rows_per_ray, dvh, PN_WIDTH_COND, S);
+        PN_CHECK_LAUNCH();
+        const float* S2 = S;
+        if (R > view_rows) {  // rays cycle through the view rows (env light: ray b*D + d looks along direction d)
+            RUN(pn_launch_reduce_rows(S, R / view_rows, view_rows * PN_WIDTH_COND, (int)view_rows, PN_WIDTH_COND,
+                                      PN_WIDTH_COND, S2buf, PN_WIDTH_COND, 0, fold_scratch, ws));
+            S2 = S2buf;
+        }
+        hipLaunchKernelGGL(k_view_wgrad, dim3(PN_WIDTH_COND), dim3(256), 0, ws, view_rows, S2, viewenc, grads + L.wv, ldv);
+        PN_CHECK_LAUNCH();
+        RUN(pn_launch_reduce_rows(S2, view_rows, PN_WIDTH_COND, 1, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv,
+                                  PN_WIDTH_COND, 1, bias_scratch, ws));
     }
-    RUN(colsum_into(M, dvh, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv, partial, ws));
     {  // d bottleneck = dvh * Wv[:, :256]
         PnGemmNt g = nt(M, PN_WIDTH, dvh, PN_WIDTH_COND, wpack + P.wvm_t, PN_WIDTH_COND, PN_WIDTH_COND, dbott, PN_WIDTH);
         g.colsum = csum_slot(0);

@@ -91,7 +91,7 @@ def _mlp_backward(ev, cfg, params, wpack, d_raw_rgb, d_raw_den, v, d_mean, flat_
     one GEMM per layer."""
     import ctypes
     m_batched = ev.M * (2 if v is not None else 1) + sum(e.M * (2 if t else 1) for e, _, t in deferred)
-    n = int(_lib.load().pn_mlp_backward_work_floats(ev.M, ev.view_rows, m_batched if deferred else 0))
+    n = int(_lib.load().pn_mlp_backward_work_floats(ev.M, ev.rows_per_ray, ev.view_rows, m_batched if deferred else 0))
     work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
     nd = len(deferred)
     if nd:
@@ -294,7 +294,10 @@ class _RenderBase(torch.nn.Module):
         if self.mlp.num_density_channels != self._NC:
             raise NotImplementedError(f"{type(self).__name__} needs mlp_num_density_channels={self._NC}")
         self.noise_override = None  # tests: dict(t_rand=[B,S], u_rand=[B,S], env_rand=[1,Ne+1])
-        self.overlap_weight_grads = True  # weight-gradient GEMMs on a side stream (same results, different order of launch)
+        # weight-gradient GEMMs on a side stream: same results, different launch order.  Off by default: with the
+        # weight gradients of the three evaluations batched (below) the chip is power-limited either way and the
+        # time-shared run measured 2 % SLOWER (62.4 k vs 61.0 k rays/s at 4096 rays, 50.8 k vs 49.4 k at 512)
+        self.overlap_weight_grads = False
         self.batch_weight_grads = True    # one weight-gradient GEMM per layer over env + level-1 + level-0 rows
 
     def _noise(self, randomized, B, dev, want_env):

@@ -76,7 +76,8 @@ def test_split_k_workspace_is_monotone_in_rows():
             assert cur >= prev and cur % (n1 * n2) == 0, (rows, n1, n2)
             prev = cur
     # the workspace of one backward call covers its batched row count and every smaller one
-    assert handle.pn_mlp_backward_work_floats(8481, 257, 51143) >= handle.pn_mlp_backward_work_floats(8481, 257, 42662)
+    assert handle.pn_mlp_backward_work_floats(8481, 33, 257, 51143) >= handle.pn_mlp_backward_work_floats(8481, 33, 257, 42662) > 0
+    assert handle.pn_mlp_backward_work_floats(8481, 32, 257, 0) < 0  # not a whole number of rays
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
