@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), same guide
 # algorithmic GEMM FLOPs (MACs x 2) per ray per train step, Pano N=128
 F_PANO, F_GRAD = 1222656.0, 1016320.0
 
@@ -92,6 +93,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
+    ap.add_argument("--gemm-mode", choices=("fp32", "split"), default=None,
+                    help="fp32: exact fp32 MFMA (default); split: fp32-accurate 3-term bf16 split on the bf16 matrix cores "
+                         "(default follows PN_GEMM_MODE)")
     ap.add_argument("--overlap", choices=("on", "off"), default="off",
                     help="weight-gradient GEMMs on a side stream (on) or in line on the main stream (off)")
     args = ap.parse_args()
@@ -120,6 +124,10 @@ def main():
     import pano_nerf_amd as pn
     from pano_nerf_amd import _lib
     from pano_nerf_amd.dist import shard_bounds
+    split = (args.gemm_mode == "split") if args.gemm_mode else os.environ.get("PN_GEMM_MODE", "0")[:1] == "1"
+    _lib.load().pn_set_gemm_mode(1 if split else 0)
+    # price the NT GEMMs against the matrix-core rate of the instruction they use: fp32 MFMA, or bf16 MFMA / 6 products
+    peak_nt = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
 
     # ---- synthetic scene: 3 identity-rotation cameras, analytic HDR radiance, rays made by K1
     torch.manual_seed(4)
@@ -285,16 +293,21 @@ def main():
         out = {
             "metric": "rays/sec (train step)", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (3xbf16 split products, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"panonerf.yaml train step, synthetic {args.height}x{args.width} pano pool x3 cams, "
                                    f"{args.samples} coarse + {args.samples} fine samples, 10x10 env-light rays, "
                                    f"surface+chrom+ort loss, Adam; global batch {args.global_batch} rays "
                                    f"({hi - lo} per GPU)",
                        "global_batch": args.global_batch, "rays_per_gpu": hi - lo, "num_samples": args.samples,
                        "parallelism": f"dp{world} (rays sharded, one 2.455 MB gradient all-reduce/step)",
-                       "launch": "hip-graph replay" if not prof_live else "eager"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                       "launch": "hip-graph replay" if not prof_live else "eager",
+                       "gemm_mode": "split: x = h + m + l (bf16), six partial products on v_mfma_f32_32x32x16_bf16, fp32 "
+                                    "accumulate; weight gradients on fp32 MFMA" if split else "exact fp32 MFMA"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
+                         "peak": peak_nt if dom == "k_gemm_nt" else PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / (peak_nt if dom == "k_gemm_nt" else PEAK_F32_MFMA_TFLOPS),
+                         "traffic": traffic,
                          "avg_launch_us": avg_us, "launches": n,
                          "measured": "HIP events around every GEMM launch " + ("during the timed region" if prof_live else
                                      "on 2 eager steps right after the timed region (events cannot be recorded inside a "

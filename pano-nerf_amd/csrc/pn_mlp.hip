@@ -351,19 +351,13 @@ __global__ __launch_bounds__(256) void k_ray_colsum(int64_t R, int rows_per_ray,
     }
 }
 
-// dWv[j][256 + i] += sum_v S2[v][j] * viewenc[v][i]   (j < 128, i < 27): block = one j, 8 partial lanes per i
-__global__ __launch_bounds__(256) void k_view_wgrad(int64_t V, const float* S2, const float* viewenc, float* dWv, int ldw) {
-    __shared__ float red[8][32];
-    const int j = blockIdx.x, i = threadIdx.x & 31, part = threadIdx.x >> 5;
-    float s = 0.f;
-    if (i < PN_VIEW_DIM)
-        for (int64_t v = part; v < V; v += 8) s += S2[v * PN_WIDTH_COND + j] * viewenc[v * PN_VIEW_DIM + i];
-    red[part][i] = s;
-    __syncthreads();
-    if (part == 0 && i < PN_VIEW_DIM) {
-        float t = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
-        dWv[(int64_t)j * ldw + PN_WIDTH + i] += t;
-    }
+// VE[v][i] = viewenc[v][i] padded to 32 columns (16-B rows for the TN GEMM dWv[:, 256:] = S2^T VE, one row per RAY)
+__global__ void k_pad_viewenc(int64_t V, const float* viewenc, float* VE) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= V * 32) return;
+    const int64_t v = idx >> 5;
+    const int i = (int)(idx & 31);
+    VE[idx] = (i < PN_VIEW_DIM) ? viewenc[v * PN_VIEW_DIM + i] : 0.f;
 }
 
 struct BiasOffsets {
@@ -697,7 +691,7 @@ static int64_t slab_floats(int64_t rows) {
 // per-ray sums of the view-layer gradient: S [R][128], folded S2 [view_rows][128], reduction scratch
 static int64_t view_sum_floats(int64_t M, int rows_per_ray, int64_t view_rows) {
     const int64_t R = M / rows_per_ray;
-    int64_t n = R * PN_WIDTH_COND + view_rows * PN_WIDTH_COND + 64 * PN_WIDTH_COND;
+    int64_t n = R * PN_WIDTH_COND + view_rows * PN_WIDTH_COND + 64 * PN_WIDTH_COND + view_rows * 32 + PN_WIDTH_COND * 32;
     if (R > view_rows && view_rows <= 1024) n += 64 * view_rows * PN_WIDTH_COND;
     return (n + 3) & ~(int64_t)3;
 }
@@ -772,7 +766,9 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     float* S = w;
     float* S2buf = S + R * PN_WIDTH_COND;
     float* bias_scratch = S2buf + view_rows * PN_WIDTH_COND;
-    float* fold_scratch = (R > view_rows && view_rows <= 1024) ? bias_scratch + 64 * PN_WIDTH_COND : nullptr;
+    float* VE = bias_scratch + 64 * PN_WIDTH_COND;      // [view_rows][32]
+    float* vw_tmp = VE + view_rows * 32;                // [128][32]
+    float* fold_scratch = (R > view_rows && view_rows <= 1024) ? vw_tmp + PN_WIDTH_COND * 32 : nullptr;
     w += view_sum_floats(M, rows_per_ray, view_rows);
     float* dden = w; w += Mp * 8;
     float* sdot = w; w += Mp;
@@ -902,8 +898,13 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
                                       PN_WIDTH_COND, S2buf, PN_WIDTH_COND, 0, fold_scratch, ws));
             S2 = S2buf;
         }
-        hipLaunchKernelGGL(k_view_wgrad, dim3(PN_WIDTH_COND), dim3(256), 0, ws, view_rows, S2, viewenc, grads + L.wv, ldv);
+        hipLaunchKernelGGL(k_pad_viewenc, dim3(nblk(view_rows * 32, 256)), dim3(256), 0, ws, view_rows, viewenc, VE);
         PN_CHECK_LAUNCH();
+        {  // [128][32] product over the rays; only the first 27 columns exist in the parameter: land it in scratch, then add
+            PnSegTn sg{S2, VE, PN_WIDTH_COND, 32, view_rows};
+            RUN(pn_launch_gemm_tn(&sg, 1, PN_WIDTH_COND, 32, vw_tmp, 32, 0, slab, slab_avail, ws));
+            RUN(pn_launch_reduce_rows(vw_tmp, 1, 0, PN_WIDTH_COND, PN_VIEW_DIM, 32, grads + L.wv + PN_WIDTH, ldv, 1, nullptr, ws));
+        }
         RUN(pn_launch_reduce_rows(S2, view_rows, PN_WIDTH_COND, 1, PN_WIDTH_COND, PN_WIDTH_COND, grads + L.bv,
                                   PN_WIDTH_COND, 1, bias_scratch, ws));
     }
