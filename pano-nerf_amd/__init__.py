@@ -7,6 +7,7 @@ Public surface (mirrors the reference's names):
     pano_loss, mip_loss           systems/panonerf_system.py:15-75, systems/mipnerf_system.py:22-53
     FlatAdam, mip_lr              systems/base_system.py:82-87, utils/lr_schedule.py:51-59
     render_image                  systems/panonerf_system.py:133-192
+    metrics, io_exr               utils/metrics.py:210-397 (calc_* / calc_ws_*), utils/io_exr.py:6-47
 """
 __version__ = "0.1.0"
 
@@ -16,3 +17,4 @@ from .render import PanoMipNeRF, MipNeRF  # noqa
 from .loss import pano_loss, mip_loss  # noqa
 from .optim import FlatAdam, mip_lr  # noqa
 from .renderer import render_image  # noqa
+from . import metrics, io_exr  # noqa

@@ -285,3 +285,30 @@ def test_split_gemm_mode_parity(golden):
         assert float(err.max()) < 3e-7, float(err.max())
     finally:
         _lib.load().pn_set_gemm_mode(0)
+
+
+def test_autocast_call_pattern_is_fp32_inside(golden):
+    """Upstream trains under Lightning '16-mixed': forward runs inside torch.autocast and `env_rays` arrives as fp16.
+    The drop-in computes in fp32 regardless (custom_fwd casts the inputs), so the outputs and the gradients are those
+    of the plain call, bit for bit."""
+    import pano_nerf_amd as pn
+    s = golden("stages_B64_N32")
+    rays, env = to_dev(rays_of(s)), to_dev(env_of(golden))
+    env16 = type(env)(*[x.half() for x in env])  # the loader stores the lit rays as fp16 (pano_datasets.py:218-263)
+    gt = torch.from_numpy(s["rgbs"]).to(dev())
+
+    def run(autocast):
+        model = make_pano(32)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+            outs = model(rays=rays, env_rays=env16, randomized=False, white_bkgd=False, enable_surf=True,
+                         use_ort_loss=True)
+            loss, _ = pn.pano_loss(outs, rays.lossmult, gt)
+        loss.backward()
+        return outs, loss.detach(), model.mlp.last_flat_grad.clone()
+
+    o0, l0, g0 = run(False)
+    o1, l1, g1 = run(True)
+    for a, b in zip(o0[1], o1[1]):
+        if a is not None:
+            assert b.dtype == torch.float32 and torch.equal(a, b)
+    assert torch.equal(l0, l1) and torch.equal(g0, g1)
