@@ -149,6 +149,69 @@ __device__ __forceinline__ void nt_store(float* As, float* Bs, int tid, const Nt
     }
 }
 
+// One row-group step of the shared epilogue: lanes (lane >> 4) pick one of 4 rows, (lane & 15) a float4 of the wave's
+// 64 columns; reads the transposed value from the wave's LDS slab and applies bias / per-ray bias / addend / ReLU /
+// gate / mask bits / mask emission, stores, and adds to the running column sums.
+__device__ __forceinline__ void nt_epi_row(const PnGemmNt& g, const float* Ls, int flags, int lrow, int64_t row, int col4,
+                                           int gcol, bool col_ok, const f32x4& bias4, f32x4& csum, int lane) {
+    const bool ok = col_ok && row < g.M;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Ls + lrow * EPL + col4);
+    v += bias4;
+    if (ok) {
+        if (flags & PN_EPI_ROWBIAS) {
+            int64_t ray = row / g.rows_per_ray;
+            if (g.rb_mod > 0) ray %= g.rb_mod;
+            v += *reinterpret_cast<const f32x4*>(g.rowbias + ray * g.ldrb + gcol);
+        }
+        if (flags & PN_EPI_ADDC) v += *reinterpret_cast<const f32x4*>(g.addc + row * g.ldadd + gcol);
+    }
+    if (flags & PN_EPI_RELU) {
+        v[0] = fmaxf(v[0], 0.f);
+        v[1] = fmaxf(v[1], 0.f);
+        v[2] = fmaxf(v[2], 0.f);
+        v[3] = fmaxf(v[3], 0.f);
+    }
+    if ((flags & PN_EPI_GATE) && ok) {
+        f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + row * g.ldg + gcol);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = gt[c] > 0.f ? v[c] : 0.f;
+    }
+    if ((flags & PN_EPI_GATEBITS) && ok) {
+        uint32_t w = g.gate_bits[row * PN_MASK_WORDS + (gcol >> 5)];
+        const int bi = (gcol >> 2) & 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = ((w >> (c * 8 + bi)) & 1u) ? v[c] : 0.f;
+    }
+    if (flags & PN_EPI_MASKOUT) {  // all 64 lanes take part in the ballots
+        uint32_t word = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned long long b = __ballot(v[c] > 0.f);
+            word |= (uint32_t)((b >> ((lane >> 3) * 8)) & 0xffull) << (c * 8);
+        }
+        if (ok && (lane & 7) == 0) g.mask_out[row * PN_MASK_WORDS + (gcol >> 5)] = word;
+    }
+    if (ok) {
+        if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + gcol) = v;
+        csum += v;
+    }
+}
+// column sums of one wave's 64 rows -> colsum[(m0 / 64 + wm)][gcol .. gcol + 3]
+__device__ __forceinline__ void nt_epi_colsum(const PnGemmNt& g, f32x4 csum, int64_t m0, int wm, int gcol, bool col_ok,
+                                              int lane) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x = csum[c];
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        csum[c] = x;
+    }
+    if (lane < 16 && col_ok) {
+        const int64_t prow = (m0 / 64) + wm;
+        *reinterpret_cast<f32x4*>(g.colsum + prow * g.N + gcol) = csum;
+    }
+}
+
 // Shared epilogue of the NT kernels (see the comment inside).  `smem` is the (now idle) staging LDS, at least
 // 4 * 32 * EPL floats.
 template <int NT, int OFF>
@@ -178,64 +241,11 @@ __device__ __forceinline__ void nt_epilogue_t(const PnGemmNt& g, f32x16 (&acc)[2
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int lrow = (lane >> 4) + 4 * i;
-            const int64_t row = m0 + wm * 64 + tm * 32 + lrow;
-            const bool ok = col_ok && row < g.M;
-            f32x4 v = *reinterpret_cast<const f32x4*>(Ls + lrow * EPL + col4);
-            v += bias4;
-            if (ok) {
-                if (flags & PN_EPI_ROWBIAS) {
-                    int64_t ray = row / g.rows_per_ray;
-                    if (g.rb_mod > 0) ray %= g.rb_mod;
-                    v += *reinterpret_cast<const f32x4*>(g.rowbias + ray * g.ldrb + gcol);
-                }
-                if (flags & PN_EPI_ADDC) v += *reinterpret_cast<const f32x4*>(g.addc + row * g.ldadd + gcol);
-            }
-            if (flags & PN_EPI_RELU) {
-                v[0] = fmaxf(v[0], 0.f);
-                v[1] = fmaxf(v[1], 0.f);
-                v[2] = fmaxf(v[2], 0.f);
-                v[3] = fmaxf(v[3], 0.f);
-            }
-            if ((flags & PN_EPI_GATE) && ok) {
-                f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + row * g.ldg + gcol);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = gt[c] > 0.f ? v[c] : 0.f;
-            }
-            if ((flags & PN_EPI_GATEBITS) && ok) {
-                uint32_t w = g.gate_bits[row * PN_MASK_WORDS + (gcol >> 5)];
-                const int bi = (gcol >> 2) & 7;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = ((w >> (c * 8 + bi)) & 1u) ? v[c] : 0.f;
-            }
-            if (flags & PN_EPI_MASKOUT) {  // all 64 lanes take part in the ballots
-                uint32_t word = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    unsigned long long b = __ballot(v[c] > 0.f);
-                    word |= (uint32_t)((b >> ((lane >> 3) * 8)) & 0xffull) << (c * 8);
-                }
-                if (ok && (lane & 7) == 0) g.mask_out[row * PN_MASK_WORDS + (gcol >> 5)] = word;
-            }
-            if (ok) {
-                if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + gcol) = v;
-                csum += v;
-            }
+            nt_epi_row(g, Ls, flags, lrow, m0 + wm * 64 + tm * 32 + lrow, col4, gcol, col_ok, bias4, csum, lane);
         }
         __syncthreads();
     }
-    if (flags & PN_EPI_COLSUM) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float x = csum[c];
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
-            csum[c] = x;
-        }
-        if (lane < 16 && col_ok) {
-            const int64_t prow = (m0 / 64) + wm;
-            *reinterpret_cast<f32x4*>(g.colsum + prow * g.N + gcol) = csum;
-        }
-    }
+    if (flags & PN_EPI_COLSUM) nt_epi_colsum(g, csum, m0, wm, gcol, col_ok, lane);
 }
 
 __device__ __forceinline__ void nt_epilogue(const PnGemmNt& g, f32x16 (&acc)[2][2], float* smem, int64_t m0, int n0,
@@ -321,6 +331,19 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
     nt_epilogue(g, acc, smem, m0, n0, lane, wid, wm, wn);
 }
 
+#ifdef PN_TRACE_NT  // debug build only (PN_EXTRA=-DPN_TRACE_NT): per-workgroup phase stamps of k_gemm_nt_dma
+__device__ unsigned long long g_nt_trace[16384 * 5];
+extern "C" int pn_trace_read(unsigned long long* out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_trace), sizeof(unsigned long long) * 5 * nblocks) == hipSuccess ? 0 : -4;
+}
+#define NT_STAMP(i)                                                                              \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 16384) g_nt_trace[blockIdx.x * 5 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define NT_STAMP(i)
+#endif
+
 // ---- NT with LDS-DMA staging ------------------------------------------------------------------------
 // K-chunks of 16 floats (64-B rows).  global_load_lds_dwordx4 fills LDS lane-linearly (64 lanes x 16 B = 16 rows
 // per wave-instruction), so the bank-conflict swizzle goes on the per-lane SOURCE address: LDS slot q' of row r
@@ -329,6 +352,7 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
 #define DK 16
 __global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n, int ntiles) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 32 * EPL];  // 34 816 B >= 2 buffers x (A + B) x 128 x 16 floats
+    NT_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int nc0 = g.seg[0].K / DK;
@@ -384,6 +408,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n,
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    NT_STAMP(1);
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
@@ -407,7 +432,13 @@ __global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next chunk has landed
         __syncthreads();
     }
+    NT_STAMP(2);
     nt_epilogue(g, acc, smem, m0, n0, lane, wid, wm, wn);
+    NT_STAMP(3);
+#ifdef PN_TRACE_NT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NT_STAMP(4);
+#endif
 }
 
 // ---- NT on the bf16 matrix cores with fp32 accuracy: 3-term split ------------------------------------------
@@ -602,16 +633,22 @@ __global__ __launch_bounds__(128 * WM, 2) void k_gemm_nt_s3w(PnGemmNt g, S3wArgs
     int64_t ar0 = m0 + srow, ar1 = ar0 + RM / 2;
     ar0 = ar0 < g.M ? ar0 : g.M - 1;
     ar1 = ar1 < g.M ? ar1 : g.M - 1;
-    f32x4 ra[2];
-    auto load_a = [&](int c) {
+    // A is fetched TWO chunks ahead (two register sets): at bf16 speed a 16-wide chunk lasts ~1.3 us, less than the
+    // loaded HBM latency, so a one-chunk prefetch leaves the matrix cores waiting on every chunk
+    struct ARegs {
+        f32x4 v[2];
+    };
+    ARegs rs0, rs1;
+    auto load_a = [&](int c, ARegs& r) {
         const bool s1 = c >= nc0;
         const float* A = s1 ? A1 : A0;
         const int lda = s1 ? lda1 : lda0;
         const int k = (s1 ? c - nc0 : c) * SK + sq * 4;
-        ra[0] = *reinterpret_cast<const f32x4*>(A + ar0 * lda + k);
-        ra[1] = *reinterpret_cast<const f32x4*>(A + ar1 * lda + k);
+        r.v[0] = *reinterpret_cast<const f32x4*>(A + ar0 * lda + k);
+        r.v[1] = *reinterpret_cast<const f32x4*>(A + ar1 * lda + k);
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf, const ARegs& r) {
+        const f32x4* ra = r.v;
         unsigned short* as = smem_s + buf * BUF;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -658,17 +695,20 @@ __global__ __launch_bounds__(128 * WM, 2) void k_gemm_nt_s3w(PnGemmNt g, S3wArgs
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    load_a(0);
+    load_a(0, rs0);
     dma_b(0, 0);
-    store_a(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nchunks > 1) load_a(1, rs1);
+    store_a(0, rs0);
+    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // B(0) landed; A(1) may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+    // one chunk: B(c+1) by DMA and A(c+2) into `rfar` are issued first, then the MFMAs of chunk c, then A(c+1) (in
+    // `rnear`, fetched during the previous chunk) is split into the other LDS buffer
+    auto chunk = [&](int c, ARegs& rnear, ARegs& rfar) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) {
-            if (!(g.flags & 0x800)) load_a(c + 1);  // ablation: no A loads
-            if (!(g.flags & 0x1000)) dma_b(c + 1, buf ^ 1);  // ablation: no B DMA
-        }
+        const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
+        if (more1 && !(g.flags & 0x1000)) dma_b(c + 1, buf ^ 1);  // 0x1000: ablation, no B DMA
+        if (more2 && !(g.flags & 0x800)) load_a(c + 2, rfar);     // 0x800: ablation, no A loads
         const unsigned short* as = smem_s + buf * BUF;
         const unsigned short* bs = as + 3 * RM * SK;
         bf16x8 a[2][3];
@@ -695,12 +735,145 @@ __global__ __launch_bounds__(128 * WM, 2) void k_gemm_nt_s3w(PnGemmNt g, S3wArgs
                 acc[tm][tn] = v;
             }
         }
-        if (c + 1 < nchunks) store_a(buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (more1) store_a(buf ^ 1, rnear);
+        // __syncthreads() carries a workgroup fence that drains vmcnt to 0, which would wait for the A(c+2) loads at
+        // every chunk; the raw barrier only needs this wave's LDS writes and its B(c+1) DMAs to have landed
+        if (more2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, rs1, rs0);                       // chunk c reads LDS; rs1 = A(c+1); rs0 <- A(c+2)
+        if (c + 1 < nchunks) chunk(c + 1, rs0, rs1);
     }
     nt_epilogue_t<4, 0>(g, acc, reinterpret_cast<float*>(smem_s), m0, wn * 128, lane, wid, wm, 0);
     nt_epilogue_t<4, 2>(g, acc, reinterpret_cast<float*>(smem_s), m0, wn * 128 + 64, lane, wid, wm, 0);
+}
+
+// ---- split kernel, all-DMA staging: 256 x 256 tile, fp32 A by LDS-DMA, three chunks in the ring ----------------
+// At bf16 speed a 16-wide chunk of this tile is ~1.3 us of MFMA work, shorter than the loaded HBM latency, and
+// hipcc drains vmcnt to 0 at the first use of an ordinary global load while an LDS-DMA is in flight — so register
+// staging of A (k_gemm_nt_s3w) leaves the matrix cores waiting on every chunk (PMC: MFMA busy 40 %, waves parked
+// 34 %).  Here BOTH operands arrive by LDS-DMA: A as raw fp32 rows (the image of k_gemm_nt_dma, swizzle on the source
+// address), B as the pre-split bf16 planes; a ring of three buffers keeps two chunks in flight behind the one being
+// multiplied, retired by a COUNTED vmcnt and a raw s_barrier (no fence, hence no vmcnt(0)).  Each wave splits the A
+// fragments it needs in registers (16 values per lane and chunk), so there are no A planes in LDS at all.
+#define S3F_NB 3
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+    bf16x4 h0, m0, l0, h1, m1, l1;
+    split4(x0, h0, m0, l0);
+    split4(x1, h1, m1, l1);
+    h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    m = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+    l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(512, 2) void k_gemm_nt_s3f(PnGemmNt g, S3wArgs w, int ntiles) {
+    // per ring slot: raw A [256 rows][16 floats] (16 KB) then B planes 3 x [256][16] bf16 (24 KB)
+    constexpr int A_FLOATS = 256 * SK, B_SHORTS = 3 * 256 * SK;
+    constexpr int SLOT_BYTES = A_FLOATS * 4 + B_SHORTS * 2;  // 40 960
+    __shared__ __attribute__((aligned(16))) unsigned char smem_b[S3F_NB * SLOT_BYTES];  // 120 KB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nc0 = g.seg[0].K / SK;
+    const int nc1 = (g.nseg > 1) ? g.seg[1].K / SK : 0;
+    const int nchunks = nc0 + nc1;
+    const float* const A0 = g.seg[0].A;
+    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb;
+    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
+    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
+    const unsigned short* const P0 = w.bp[0].base;
+    const unsigned short* const P1 = g.nseg > 1 ? w.bp[1].base : P0;
+    const int64_t ps0 = w.bp[0].stride, ps1 = g.nseg > 1 ? w.bp[1].stride : ps0;
+    const int64_t m0 = (int64_t)blockIdx.x * 256;  // one tile column: N == 256
+
+    // A DMA: 16 pieces of 16 rows per chunk, wave w moves pieces w and w + 8; lane -> (row = lane >> 2, slot = lane & 3);
+    // slot s of local row r holds source k-piece s ^ ((r >> 2) & 3)
+    const int arow_l = lane >> 2;
+    const int aq = (lane & 3) ^ ((arow_l >> 2) & 3);
+    int64_t arow0 = m0 + wid * 16 + arow_l, arow1 = arow0 + 128;
+    arow0 = arow0 < g.M ? arow0 : g.M - 1;
+    arow1 = arow1 < g.M ? arow1 : g.M - 1;
+    // B DMA: 3 planes x 8 pieces of 32 rows; wave w moves piece w of every plane (layout of k_gemm_nt_s3w)
+    const int dr = lane >> 1;
+    const int dsp = (lane & 1) ^ ((dr >> 3) & 1);
+    auto stage = [&](int c, int slot) {
+        const bool s1 = c >= nc0;
+        const float* A = s1 ? A1 : A0;
+        const int lda = s1 ? lda1 : lda0;
+        const unsigned short* P = s1 ? P1 : P0;
+        const int64_t ps = s1 ? ps1 : ps0;
+        const int ldb = s1 ? ldb1 : ldb0;
+        const int kc = (s1 ? c - nc0 : c) * SK;
+        unsigned char* base = smem_b + slot * SLOT_BYTES;
+        float* as = reinterpret_cast<float*>(base);
+        unsigned short* bs = reinterpret_cast<unsigned short*>(base + A_FLOATS * 4);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + arow0 * lda + kc + aq * 4), (lds_ptr_t)(as + (wid * 16) * SK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + arow1 * lda + kc + aq * 4), (lds_ptr_t)(as + (wid * 16 + 128) * SK), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(P + p * ps + (int64_t)(wid * 32 + dr) * ldb + kc + dsp * 8),
+                                             (lds_ptr_t)(bs + (p * 256 + wid * 32) * SK), 16, 0, 0);
+    };  // 5 DMA instructions per wave and chunk
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int asw = (fr >> 2) & 3;  // rows wm*64 + tt*32 + fr: the multiples of 32 do not change (r >> 2) & 3
+    stage(0, 0);
+    if (nchunks > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    int slot = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more2 = c + 2 < nchunks;
+        int slot2 = slot + 2;
+        slot2 = slot2 >= S3F_NB ? slot2 - S3F_NB : slot2;
+        if (more2) stage(c + 2, slot2);  // that slot held chunk c - 1: every wave left it before the last barrier
+        const unsigned char* base = smem_b + slot * SLOT_BYTES;
+        const float* as = reinterpret_cast<const float*>(base);
+        const unsigned short* bs = reinterpret_cast<const unsigned short*>(base + A_FLOATS * 4);
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const float* row = as + (wm * 64 + tt * 32 + fr) * SK;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + (((2 * fh) ^ asw) << 2));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + (((2 * fh + 1) ^ asw) << 2));
+            split8(x0, x1, a[tt][0], a[tt][1], a[tt][2]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[p] = *reinterpret_cast<const bf16x8*>(bs + s3w_off(p, 256, wn * 128 + tn * 32 + fr, fh));
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                f32x16 v = acc[tm][tn];  // small terms first
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[2], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[0], v, 0, 0, 0);
+                acc[tm][tn] = v;
+            }
+        }
+        // chunk c + 1 (issued one iteration ago) must have landed; chunk c + 2 (5 DMAs, just issued) stays in flight
+        if (more2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        slot = slot + 1 >= S3F_NB ? 0 : slot + 1;
+    }
+    nt_epilogue_t<4, 0>(g, acc, reinterpret_cast<float*>(smem_b), m0, wn * 128, lane, wid, wm, 0);
+    nt_epilogue_t<4, 2>(g, acc, reinterpret_cast<float*>(smem_b), m0, wn * 128 + 64, lane, wid, wm, 0);
 }
 
 static int g_gemm_mode = -1;  // 0 = exact fp32 MFMA, 1 = 3-term bf16 split; -1 = read PN_GEMM_MODE on first use
@@ -755,7 +928,8 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
                ((reinterpret_cast<uintptr_t>(wa.bp[i].base) & 15) == 0) && (wa.bp[i].stride % 8 == 0);
     if (wide && !(g_dbg & 512)) {
         const unsigned tiles256 = (unsigned)((g.M + 255) / 256);
-        hipLaunchKernelGGL(k_gemm_nt_s3w<4>, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
+        if (g_dbg & 0x2000) hipLaunchKernelGGL(k_gemm_nt_s3w<4>, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
+        else hipLaunchKernelGGL(k_gemm_nt_s3f, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
     } else if (wide) hipLaunchKernelGGL(k_gemm_nt_s3w<2>, dim3((unsigned)tiles_m), dim3(256), 0, s, gg, wa, (int)tiles_m);
     else if (split) hipLaunchKernelGGL(k_gemm_nt_s3, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
     else if (dma) hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);

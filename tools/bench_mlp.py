@@ -7,6 +7,11 @@ import pano_nerf_amd as pn
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 M = 524288; N = 128; B = M // N
 model = pn.PanoMipNeRF(num_samples=N, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5).to(dev)
+if os.environ.get("PN_ZERO_WEIGHTS"):  # power / clock experiment: all-zero operands through the same instruction stream
+    with torch.no_grad():
+        model.mlp.flat_params().zero_()
+    from pano_nerf_amd.mlp import mark_dirty
+    mark_dirty(model.mlp)
 mean = torch.randn(M, 3, device=dev); cov = torch.rand(M, 3, device=dev) * 1e-3; vd = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
 Mp = int(lib.load().pn_pad_rows(M))
 E = lambda *s: torch.empty(*s, device=dev)
@@ -24,8 +29,8 @@ def timeit(n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 flop = M * 1222656.0
-for mode, dbg, name in ((0, 0, "fp32 mfma"), (1, 0, "split"), (1, 0x400, "split, cheap conversion"), (1, 0x800, "split, no A loads"),
-                        (1, 0x1000, "split, no B dma"), (1, 0x1c00, "split, all three off"), (1, 256, "split, narrow kernel only"), (1, 512, "split, 128-row wide kernel")):
+for mode, dbg, name in ((0, 0, "fp32 mfma"), (1, 0, "split (all-DMA ring kernel)"), (1, 0x2000, "split, register-staged A (s3w<4>)"),
+                        (1, 256, "split, narrow kernel only"), (1, 512, "split, 128-row wide kernel")):
     lib.load().pn_set_gemm_mode(mode)
     lib.load().pn_prof_enable(dbg << 8)
     flat = model.mlp.flat_params(); wpack = model.mlp.packed(st)
