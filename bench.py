@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--cpu-rays", type=int, default=96)
+    ap.add_argument("--cpu-rays", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
