@@ -237,13 +237,16 @@ __device__ __forceinline__ void nt_epilogue_t(const PnGemmNt& g, f32x16 (&acc)[2
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Ls[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPL + tn * 32 + (lane & 31)] = acc[tm][OFF + tn][r];
-        __syncthreads();
+        // The slab is private to this wave and a wave's LDS instructions execute in order: no workgroup barrier is
+        // needed between the transposed write and the row reads (a __syncthreads() here also carries a fence that
+        // waits for the previous slab's global stores).
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int lrow = (lane >> 4) + 4 * i;
             nt_epi_row(g, Ls, flags, lrow, m0 + wm * 64 + tm * 32 + lrow, col4, gcol, col_ok, bias4, csum, lane);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     if (flags & PN_EPI_COLSUM) nt_epi_colsum(g, csum, m0, wm, gcol, col_ok, lane);
 }
