@@ -840,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_s3f(PnGemmNt g, S3wArgs w, i
         const bool more2 = c + 2 < nchunks;
         int slot2 = slot + 2;
         slot2 = slot2 >= S3F_NB ? slot2 - S3F_NB : slot2;
-        if (more2) stage(c + 2, slot2);  // that slot held chunk c - 1: every wave left it before the last barrier
+        if (more2 && !(g.flags & 0x800)) stage(c + 2, slot2);  // that slot held chunk c - 1 (0x800: ablation, no DMA)
         const unsigned char* base = smem_b + slot * SLOT_BYTES;
         const float* as = reinterpret_cast<const float*>(base);
         const unsigned short* bs = reinterpret_cast<const unsigned short*>(base + A_FLOATS * 4);
@@ -850,7 +850,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_s3f(PnGemmNt g, S3wArgs w, i
             const float* row = as + (wm * 64 + tt * 32 + fr) * SK;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + (((2 * fh) ^ asw) << 2));
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + (((2 * fh + 1) ^ asw) << 2));
-            split8(x0, x1, a[tt][0], a[tt][1], a[tt][2]);
+            if (g.flags & 0x10000) {  // ablation: no split arithmetic (three copies of the raw bits)
+                bf16x8 t;
+                __builtin_memcpy(&t, &x0, 16);
+                a[tt][0] = a[tt][1] = a[tt][2] = t;
+                a[tt][1][0] = (__bf16)x1[0];
+            } else {
+                split8(x0, x1, a[tt][0], a[tt][1], a[tt][2]);
+            }
         }
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
@@ -858,6 +865,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_s3f(PnGemmNt g, S3wArgs w, i
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 b[p] = *reinterpret_cast<const bf16x8*>(bs + s3w_off(p, 256, wn * 128 + tn * 32 + fr, fh));
+            if (g.flags & 0x8000) {  // ablation: no MFMAs (keep the fragments alive)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) acc[tm][tn][0] += (float)a[tm][0][0] + (float)a[tm][1][1] + (float)a[tm][2][2] + (float)b[0][0] + (float)b[1][1] + (float)b[2][2];
+                continue;
+            }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 f32x16 v = acc[tm][tn];  // small terms first
@@ -922,7 +934,7 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     bool dma = !(g_dbg & 64) && !(g.flags & 0x200);
     for (int i = 0; i < g.nseg; ++i) dma = dma && (g.seg[i].K % DK == 0);
     bool split = gemm_mode() == 1 && !(g.flags & 0x200);
-    if (g_dbg & 0x1c00) gg.flags |= (g_dbg & 0x1c00);  // split-kernel ablations
+    if (g_dbg & 0x19c00) gg.flags |= (g_dbg & 0x19c00);  // split-kernel ablations
     for (int i = 0; i < g.nseg; ++i) split = split && (g.seg[i].K % SK == 0);
     S3wArgs wa;
     bool wide = split && g.N == 256 && !(g_dbg & 256);
