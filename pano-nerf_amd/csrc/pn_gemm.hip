@@ -335,16 +335,21 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
 }
 
 #ifdef PN_TRACE_NT  // debug build only (PN_EXTRA=-DPN_TRACE_NT): per-workgroup phase stamps of k_gemm_nt_dma
-__device__ unsigned long long g_nt_trace[16384 * 5];
+__device__ unsigned long long g_nt_trace[16384 * 8];
 extern "C" int pn_trace_read(unsigned long long* out, int nblocks) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_trace), sizeof(unsigned long long) * 5 * nblocks) == hipSuccess ? 0 : -4;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_trace), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -4;
 }
 #define NT_STAMP(i)                                                                              \
     do {                                                                                         \
-        if (threadIdx.x == 0 && blockIdx.x < 16384) g_nt_trace[blockIdx.x * 5 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0 && blockIdx.x < 16384) g_nt_trace[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define NT_CLOCK(i)                                                                              \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 16384) g_nt_trace[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define NT_STAMP(i)
+#define NT_CLOCK(i)
 #endif
 
 // ---- NT with LDS-DMA staging ------------------------------------------------------------------------
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     NT_STAMP(1);
+    NT_CLOCK(5);
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
@@ -436,6 +442,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n,
         __syncthreads();
     }
     NT_STAMP(2);
+    NT_CLOCK(6);
     nt_epilogue(g, acc, smem, m0, n0, lane, wid, wm, wn);
     NT_STAMP(3);
 #ifdef PN_TRACE_NT
