@@ -318,7 +318,8 @@ def main():
                                   "all launches on one stream (no time sharing between kernels).  ") +
                                  "`peak` is the 2.4 GHz datasheet figure; under the power cap the same k_gemm_nt binary runs "
                                  "126 TF on zero/constant operands and 101 TF on N(0,1) operands (tools/bench_clock.py, "
-                                 "profiles/r01_clock_vs_data.txt)",
+                                 "profiles/r01_clock_vs_data.txt) and sustains a 2.10 GHz shader clock inside its K loop "
+                                 "(tools/trace_nt.py, profiles/r01_nt_phase_trace_K256.txt), i.e. 137.5 TF are available",
                          "isolated": iso,
                          "flop_per_launch": fl / max(n, 1),
                          "other": {k: {"total_ms": v[0], "launches": v[1],
