@@ -585,11 +585,9 @@ __global__ __launch_bounds__(256, 3) void k_gemm_nt_s3(PnGemmNt g, int tiles_n, 
     nt_epilogue(g, acc, reinterpret_cast<float*>(smem_s), m0, n0, lane, wid, wm, wn);
 }
 
-// ---- wide split kernel: 128 x 256 output tile, pre-split weight planes by LDS-DMA ---------------------------
-// For the N = 256 layers.  4 waves as 2 x 2, each a 64 x 128 slab (2 x 4 MFMA tiles, 128 accumulator registers):
-// the A panel (activations) is split once per 256 output columns, the B operand (weights) arrives as bf16 planes
-// prepared once per optimizer step by pn_pack_weights and is moved global -> LDS by DMA with the swizzle on the
-// source address.  48 MFMAs per wave between barriers.
+// ---- pre-split weight planes (N = 256 layers) ------------------------------------------------------------------
+// The B operand (weights) arrives as bf16 planes prepared once per optimizer step by pn_pack_weights and is moved
+// global -> LDS by DMA with the swizzle on the source address.
 struct PlaneRef {
     const unsigned short* base;  // plane 0 of the element the fp32 pointer addresses; plane p at + p * stride
     int64_t stride;
@@ -619,150 +617,10 @@ __device__ __forceinline__ int s3w_off(int plane, int rows, int row, int piece) 
     return ((plane * rows + row) * SK) + ((piece ^ ((row >> 3) & 1)) << 3);
 }
 
-template <int WM>
-__global__ __launch_bounds__(128 * WM, 2) void k_gemm_nt_s3w(PnGemmNt g, S3wArgs w, int ntiles) {
-    constexpr int RM = 64 * WM;  // rows of the block tile
-    // per buffer: A planes 3 x [128][16] bf16 (12 KB) then B planes 3 x [256][16] bf16 (24 KB)
-    __shared__ __attribute__((aligned(16))) unsigned short smem_s[2 * (3 * RM * SK + 3 * 256 * SK)];  // 72 / 96 KB
-    constexpr int BUF = 3 * RM * SK + 3 * 256 * SK;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int nc0 = g.seg[0].K / SK;
-    const int nc1 = (g.nseg > 1) ? g.seg[1].K / SK : 0;
-    const int nchunks = nc0 + nc1;
-    const float* const A0 = g.seg[0].A;
-    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb;
-    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
-    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
-    const unsigned short* const P0 = w.bp[0].base;
-    const unsigned short* const P1 = g.nseg > 1 ? w.bp[1].base : P0;
-    const int64_t ps0 = w.bp[0].stride, ps1 = g.nseg > 1 ? w.bp[1].stride : ps0;
-    const int64_t m0 = (int64_t)blockIdx.x * RM;  // one tile column: N == 256
-
-    const int sq = tid & 3, srow = tid >> 2;
-    int64_t ar0 = m0 + srow, ar1 = ar0 + RM / 2;
-    ar0 = ar0 < g.M ? ar0 : g.M - 1;
-    ar1 = ar1 < g.M ? ar1 : g.M - 1;
-    // A is fetched TWO chunks ahead (two register sets): at bf16 speed a 16-wide chunk lasts ~1.3 us, less than the
-    // loaded HBM latency, so a one-chunk prefetch leaves the matrix cores waiting on every chunk
-    struct ARegs {
-        f32x4 v[2];
-    };
-    ARegs rs0, rs1;
-    auto load_a = [&](int c, ARegs& r) {
-        const bool s1 = c >= nc0;
-        const float* A = s1 ? A1 : A0;
-        const int lda = s1 ? lda1 : lda0;
-        const int k = (s1 ? c - nc0 : c) * SK + sq * 4;
-        r.v[0] = *reinterpret_cast<const f32x4*>(A + ar0 * lda + k);
-        r.v[1] = *reinterpret_cast<const f32x4*>(A + ar1 * lda + k);
-    };
-    auto store_a = [&](int buf, const ARegs& r) {
-        const f32x4* ra = r.v;
-        unsigned short* as = smem_s + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = srow + (RM / 2) * i;
-            const int o = ((sq >> 1) ^ ((row >> 3) & 1)) * 8 + (sq & 1) * 4;
-            bf16x4 h, m, l;
-            if (g.flags & 0x400) {  // ablation: one conversion instead of the 3-term split
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = m[e] = l[e] = (__bf16)ra[i][e];
-            } else {
-                split4(ra[i], h, m, l);
-            }
-            *reinterpret_cast<bf16x4*>(as + (0 * RM + row) * SK + o) = h;
-            *reinterpret_cast<bf16x4*>(as + (1 * RM + row) * SK + o) = m;
-            *reinterpret_cast<bf16x4*>(as + (2 * RM + row) * SK + o) = l;
-        }
-    };
-    // B: 3 planes x 8 pieces (32 rows x 32 B each) per chunk; wave w issues pieces w, w+4 of every plane
-    const int dr = lane >> 1;                                      // row inside a 32-row piece
-    const int dsp = (lane & 1) ^ ((dr >> 3) & 1);                  // source 16-B piece for this lane's LDS slot
-    auto dma_b = [&](int c, int buf) {
-        const bool s1 = c >= nc0;
-        const unsigned short* P = s1 ? P1 : P0;
-        const int64_t ps = s1 ? ps1 : ps0;
-        const int ldb = s1 ? ldb1 : ldb0;
-        const int k = (s1 ? c - nc0 : c) * SK + dsp * 8;
-        unsigned short* bs = smem_s + buf * BUF + 3 * RM * SK;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int j = 0; j < 4 / WM; ++j) {
-                const int piece = wid + 2 * WM * j;  // rows 32*piece .. 32*piece + 31 (N == 256: always in range)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(P + p * ps + (int64_t)(piece * 32 + dr) * ldb + k),
-                                                 (lds_ptr_t)(bs + (p * 256 + piece * 32) * SK), 16, 0, 0);
-            }
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    load_a(0, rs0);
-    dma_b(0, 0);
-    if (nchunks > 1) load_a(1, rs1);
-    store_a(0, rs0);
-    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // B(0) landed; A(1) may still fly
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // one chunk: B(c+1) by DMA and A(c+2) into `rfar` are issued first, then the MFMAs of chunk c, then A(c+1) (in
-    // `rnear`, fetched during the previous chunk) is split into the other LDS buffer
-    auto chunk = [&](int c, ARegs& rnear, ARegs& rfar) {
-        const int buf = c & 1;
-        const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
-        if (more1 && !(g.flags & 0x1000)) dma_b(c + 1, buf ^ 1);  // 0x1000: ablation, no B DMA
-        if (more2 && !(g.flags & 0x800)) load_a(c + 2, rfar);     // 0x800: ablation, no A loads
-        const unsigned short* as = smem_s + buf * BUF;
-        const unsigned short* bs = as + 3 * RM * SK;
-        bf16x8 a[2][3];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                a[tt][p] = *reinterpret_cast<const bf16x8*>(as + s3w_off(p, RM, wm * 64 + tt * 32 + fr, fh));
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            bf16x8 b[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[p] = *reinterpret_cast<const bf16x8*>(bs + s3w_off(p, 256, wn * 128 + tn * 32 + fr, fh));
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                f32x16 v = acc[tm][tn];
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[0], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[2], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[1], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[0], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[1], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[0], v, 0, 0, 0);
-                acc[tm][tn] = v;
-            }
-        }
-        if (more1) store_a(buf ^ 1, rnear);
-        // __syncthreads() carries a workgroup fence that drains vmcnt to 0, which would wait for the A(c+2) loads at
-        // every chunk; the raw barrier only needs this wave's LDS writes and its B(c+1) DMAs to have landed
-        if (more2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-    for (int c = 0; c < nchunks; c += 2) {
-        chunk(c, rs1, rs0);                       // chunk c reads LDS; rs1 = A(c+1); rs0 <- A(c+2)
-        if (c + 1 < nchunks) chunk(c + 1, rs0, rs1);
-    }
-    nt_epilogue_t<4, 0>(g, acc, reinterpret_cast<float*>(smem_s), m0, wn * 128, lane, wid, wm, 0);
-    nt_epilogue_t<4, 2>(g, acc, reinterpret_cast<float*>(smem_s), m0, wn * 128 + 64, lane, wid, wm, 0);
-}
-
 // ---- split kernel, all-DMA staging: 256 x 256 tile, fp32 A by LDS-DMA, three chunks in the ring ----------------
 // At bf16 speed a 16-wide chunk of this tile is ~1.3 us of MFMA work, shorter than the loaded HBM latency, and
 // hipcc drains vmcnt to 0 at the first use of an ordinary global load while an LDS-DMA is in flight — so register
-// staging of A (k_gemm_nt_s3w) leaves the matrix cores waiting on every chunk (PMC: MFMA busy 40 %, waves parked
+// staging of A (an earlier kernel, removed) leaves the matrix cores waiting on every chunk (PMC: MFMA busy 40 %, waves parked
 // 34 %).  Here BOTH operands arrive by LDS-DMA: A as raw fp32 rows (the image of k_gemm_nt_dma, swizzle on the source
 // address), B as the pre-split bf16 planes; a ring of three buffers keeps two chunks in flight behind the one being
 // multiplied, retired by a COUNTED vmcnt and a raw s_barrier (no fence, hence no vmcnt(0)).  Each wave splits the A
@@ -803,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_s3f(PnGemmNt g, S3wArgs w, i
     int64_t arow0 = m0 + wid * 16 + arow_l, arow1 = arow0 + 128;
     arow0 = arow0 < g.M ? arow0 : g.M - 1;
     arow1 = arow1 < g.M ? arow1 : g.M - 1;
-    // B DMA: 3 planes x 8 pieces of 32 rows; wave w moves piece w of every plane (layout of k_gemm_nt_s3w)
+    // B DMA: 3 planes x 8 pieces of 32 rows; wave w moves piece w of every plane
     const int dr = lane >> 1;
     const int dsp = (lane & 1) ^ ((dr >> 3) & 1);
     auto stage = [&](int c, int slot) {
@@ -948,11 +806,10 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     for (int i = 0; i < g.nseg && wide; ++i)
         wide = lookup_planes(g.seg[i].B, wa.bp[i]) && (g.seg[i].ldb % 8 == 0) &&
                ((reinterpret_cast<uintptr_t>(wa.bp[i].base) & 15) == 0) && (wa.bp[i].stride % 8 == 0);
-    if (wide && !(g_dbg & 512)) {
+    if (wide) {
         const unsigned tiles256 = (unsigned)((g.M + 255) / 256);
-        if (g_dbg & 0x2000) hipLaunchKernelGGL(k_gemm_nt_s3w<4>, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
-        else hipLaunchKernelGGL(k_gemm_nt_s3f, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
-    } else if (wide) hipLaunchKernelGGL(k_gemm_nt_s3w<2>, dim3((unsigned)tiles_m), dim3(256), 0, s, gg, wa, (int)tiles_m);
+        hipLaunchKernelGGL(k_gemm_nt_s3f, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
+    }
     else if (split) hipLaunchKernelGGL(k_gemm_nt_s3, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
     else if (dma) hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
     else hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
@@ -1234,167 +1091,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tn_wide(PnTnArgs g, int tiles2,
         }
 }
 
-// ---- TN on the bf16 matrix cores with fp32 accuracy (3-term split, see k_gemm_nt_s3) ----------------------
-// Both operands are activations, so both are split in the staging path.  The MFMA wants 8 consecutive k (= rows)
-// per lane; the planes are therefore stored k-pair-major: word [kp][col] holds rows 2kp, 2kp+1 of one column as
-// two bf16 (one v_cvt_pk_bf16_f32 packs them), a thread writes its 4 columns with one ds_write_b128 per plane and
-// a fragment is four conflict-free ds_read_b32 (k-pairs 4h .. 4h+3).  16-row chunks, two LDS buffers, one barrier
-// per chunk; row / column tails are zero-filled by selects, so one kernel serves every shape.
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    unsigned u;
-    __builtin_memcpy(&u, &v, 4);
-    return u;
-}
-// exact 3-term split of two floats (rows k, k+1 of one column) into three packed words
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = pack_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = pack_bf16(r0, r1);
-    r0 -= __uint_as_float(m << 16);
-    r1 -= __uint_as_float(m & 0xffff0000u);
-    l = pack_bf16(r0, r1);
-}
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256, 3) void k_gemm_tn_s3(PnTnArgs g, int tiles2, int ntiles, int nsplit) {
-    // per buffer: X planes [3][8 kp][128 cols] u32 (12 KB), Y planes (12 KB)
-    __shared__ __attribute__((aligned(16))) unsigned smem_u[2 * 2 * 3 * 8 * 128];  // 48 KB
-    constexpr int OP = 3 * 8 * 128, BUFW = 2 * OP;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
-    const int tile = jj % ntiles;
-    const int64_t split = (int64_t)(jj / ntiles) * 8 + xcd;
-    if (split >= nsplit) return;
-    const int i0 = (tile / tiles2) * BM, j0 = (tile % tiles2) * BN;
-    const int64_t c_begin = split * (g.rows_per_split / BK);
-    int64_t c_end = c_begin + g.rows_per_split / BK;
-    if (c_end > g.chunks_total) c_end = g.chunks_total;
-
-    const int N1 = g.N1, N2 = g.N2;
-
-    TnCursor cur;
-    tn_cursor_init(g, cur, c_begin);
-    // staging: thread -> columns 4cg .. 4cg+3, k-pair rg (rows 2rg, 2rg+1 of the 16-row sub-chunk)
-    const int cg = tid & 31, rg = tid >> 5;
-    const bool xin = i0 + 4 * cg < N1, yin = j0 + 4 * cg < N2;
-    const int xc = xin ? i0 + 4 * cg : 0, yc = yin ? j0 + 4 * cg : 0;
-    f32x4 rx[2], ry[2];
-    auto load = [&](int64_t sc) {  // sub-chunk sc = 2 * chunk + half
-        const int64_t r0 = tn_cursor_seek(g, cur, sc >> 1) + (sc & 1) * 16 + 2 * rg;
-        const float* X = cur.X;
-        const float* Y = cur.Y;
-        const int ldx = cur.ldx, ldy = cur.ldy;
-        const int64_t Mseg = cur.M;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int64_t r = r0 + i;
-            const bool rin = r < Mseg;
-            const int64_t rc = rin ? r : Mseg - 1;
-            f32x4 vx = *reinterpret_cast<const f32x4*>(X + rc * ldx + xc);
-            f32x4 vy = *reinterpret_cast<const f32x4*>(Y + rc * ldy + yc);
-            rx[i] = (rin && xin) ? vx : z;
-            ry[i] = (rin && yin) ? vy : z;
-        }
-    };
-    auto store = [&](int buf) {
-        unsigned* xs = smem_u + buf * BUFW;
-        unsigned* ys = xs + OP;
-        u32x4 h, m, l;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned th, tm_, tl;
-            split_pair(rx[0][c], rx[1][c], th, tm_, tl);
-            h[c] = th;
-            m[c] = tm_;
-            l[c] = tl;
-        }
-        *reinterpret_cast<u32x4*>(xs + (0 * 8 + rg) * 128 + 4 * cg) = h;
-        *reinterpret_cast<u32x4*>(xs + (1 * 8 + rg) * 128 + 4 * cg) = m;
-        *reinterpret_cast<u32x4*>(xs + (2 * 8 + rg) * 128 + 4 * cg) = l;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned th, tm_, tl;
-            split_pair(ry[0][c], ry[1][c], th, tm_, tl);
-            h[c] = th;
-            m[c] = tm_;
-            l[c] = tl;
-        }
-        *reinterpret_cast<u32x4*>(ys + (0 * 8 + rg) * 128 + 4 * cg) = h;
-        *reinterpret_cast<u32x4*>(ys + (1 * 8 + rg) * 128 + 4 * cg) = m;
-        *reinterpret_cast<u32x4*>(ys + (2 * 8 + rg) * 128 + 4 * cg) = l;
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int64_t s_begin = 2 * c_begin, s_end = 2 * c_end;
-    if (s_begin < s_end) {
-        load(s_begin);
-        store(0);
-        __syncthreads();
-        const int fr = lane & 31, fh = lane >> 5;
-        for (int64_t sc = s_begin; sc < s_end; ++sc) {
-            const int buf = (int)((sc - s_begin) & 1);
-            if (sc + 1 < s_end) load(sc + 1);
-            const unsigned* xs = smem_u + buf * BUFW;
-            const unsigned* ys = xs + OP;
-            bf16x8 a[2][3], b[2][3];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    u32x4 va, vb;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        va[q] = xs[(p * 8 + 4 * fh + q) * 128 + wm * 64 + tt * 32 + fr];
-                        vb[q] = ys[(p * 8 + 4 * fh + q) * 128 + wn * 64 + tt * 32 + fr];
-                    }
-                    __builtin_memcpy(&a[tt][p], &va, 16);
-                    __builtin_memcpy(&b[tt][p], &vb, 16);
-                }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    f32x16 v = acc[tm][tn];
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], v, 0, 0, 0);
-                    acc[tm][tn] = v;
-                }
-            if (sc + 1 < s_end) store(buf ^ 1);
-            __syncthreads();
-        }
-    }
-    float* out = g.slab + split * (int64_t)g.N1 * g.N2;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = j0 + wn * 64 + tn * 32 + (lane & 31);
-            if (col >= g.N2) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.N1) out[(int64_t)row * g.N2 + col] = acc[tm][tn][r];
-            }
-        }
-}
-
 // Deterministic sum over a leading "partials" dimension: out[e] = sum_b src[b*stride + e'] for the
 // elements e of a [rows, cols] block.  One block = 64 elements x 4 partial lanes; grid.y splits the partials.
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* src, int64_t nb, int64_t stride, int rows, int cols,
@@ -1532,8 +1228,7 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
     g.N1 = N1;
     g.N2 = N2;
     g.chunks_total = chunks;
-    const bool s3 = gemm_mode() == 1 && (g_dbg & 2048);  // split TN: correct but slower than fp32 MFMA, experiments only
-    const bool wide = !s3 && (N1 % 128 == 0) && (N2 % 256 == 0) && !(g_dbg & 128);
+    const bool wide = (N1 % 128 == 0) && (N2 % 256 == 0) && !(g_dbg & 128);
     int nsplit = tn_splits(Mtotal, N1, N2);
     if (work_avail >= 0 && (int64_t)nsplit * N1 * N2 > work_avail) return PN_ERR_BAD_SHAPE;  // slab too small
     int64_t per = (g.chunks_total + nsplit - 1) / nsplit;
@@ -1544,9 +1239,7 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
         ProfScope prof(1, 2.0 * (double)Mtotal * N1 * N2, s);
         const int ntiles = tiles1 * tiles2;
         const int groups = (nsplit + 7) / 8;
-        if (s3) {
-            hipLaunchKernelGGL(k_gemm_tn_s3, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);
-        } else if (wide) {
+        if (wide) {
             const int t2 = N2 / 256, nt2 = (N1 / 128) * t2;
             hipLaunchKernelGGL(k_gemm_tn_wide, dim3(groups * nt2 * 8), dim3(256), 0, s, g, t2, nt2, nsplit);
         } else hipLaunchKernelGGL(k_gemm_tn, dim3(groups * ntiles * 8), dim3(256), 0, s, g, tiles2, ntiles, nsplit);

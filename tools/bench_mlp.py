@@ -30,8 +30,8 @@ def timeit(n=5):
     return e0.elapsed_time(e1) / n
 flop = M * 1222656.0
 for mode, dbg, name in ((0, 0, "fp32 mfma"), (1, 0, "split (all-DMA ring kernel)"), (1, 0x8000, "ring, no MFMAs"), (1, 0x10000, "ring, no split arithmetic"),
-                        (1, 0x18000, "ring, neither"), (1, 0x1800, "ring, no DMA"), (1, 0x2000, "split, register-staged A (s3w<4>)"),
-                        (1, 256, "split, narrow kernel only"), (1, 512, "split, 128-row wide kernel")):
+                        (1, 0x18000, "ring, neither"), (1, 0x1800, "ring, no DMA"),
+                        (1, 256, "split, narrow kernel only")):
     lib.load().pn_set_gemm_mode(mode)
     lib.load().pn_prof_enable(dbg << 8)
     flat = model.mlp.flat_params(); wpack = model.mlp.packed(st)

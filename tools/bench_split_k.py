@@ -19,7 +19,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for mode, dbg, name in ((0, 0, "fp32 mfma"), (1, 0, "split ring (s3f)"), (1, 0x2000, "split s3w<4>"), (1, 512, "split s3w<2>"), (1, 256, "split narrow")):
+for mode, dbg, name in ((0, 0, "fp32 mfma"), (1, 0, "split (narrow kernel: a free-standing B has no pre-split planes)")):
     lib.load().pn_set_gemm_mode(mode)
     lib.load().pn_prof_enable(dbg << 8)
     flat = model.mlp.flat_params(); wpack = model.mlp.packed(st)
