@@ -9,8 +9,15 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to fp32, row-major, contiguous, unless the
- *     parameter name ends in _host; the caller owns all memory, the library keeps
- *     no global state and allocates nothing;
+ *     parameter name ends in _host; the caller owns all device memory and the library
+ *     allocates none;
+ *   - process model: ONE device and ONE host thread per process (how the reference runs
+ *     under DDP).  The library keeps three small pieces of process-wide host state, none
+ *     of which is a result: the GEMM mode (pn_set_gemm_mode), a pool of hipEvent_t used to
+ *     fork / join the optional side stream and by pn_prof_*, and the address ranges of the
+ *     two weight blocks whose bf16 planes pn_pack_weights prepared (so that the split GEMM
+ *     mode can find the planes of a weight pointer).  Calls are not re-entrant across host
+ *     threads;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the
  *     call returns without synchronising (graph-capturable);
  *   - return value: 0 on success, negative PN_ERR_* otherwise (the Python shim
