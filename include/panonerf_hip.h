@@ -79,6 +79,14 @@ int pn_raygen_pano(int H, int W, const float* c2w_host /*[16] row-major 4x4*/, f
  * origins[D,3] directions[D,3] viewdirs[D,3] radii[D] lossmult[D] near[D] far[D] noise_var[D]. */
 int pn_lit_rays(int D, double radius, double near_, double far_, uint16_t* out_half, void* stream);
 
+/* Training-batch gather out of a device-resident ray pool — the host-side __getitem__ gather of
+ * datasets/pano_datasets.py:271-275 (one DataLoader worker per 56-byte ray upstream).
+ *   idx [B] int64 (device): pool row of every batch ray (out-of-range rows read row 0);
+ *   pool_host / out_host: HOST arrays of 9 device pointers in the order origins, directions, viewdirs [.,3],
+ *   radii, lossmult, near, far, noise_var [.,1], rgb [.,3]; entry 8 (rgb) may be null in both. */
+int pn_gather_rays(int64_t B, int64_t pool_rays, const int64_t* idx, const float* const* pool_host,
+                   float* const* out_host, void* stream);
+
 /* ---- sampling ----------------------------------------------------------------------
  * sample_along_rays (models/mip.py:113-151, disparity = False) + cast_rays (67-89) +
  * conical_frustum_to_gaussian (36-64, stable) + lift_gaussian (8-22, diagonal).

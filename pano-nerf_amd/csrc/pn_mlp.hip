@@ -75,20 +75,6 @@ PnPack pn_pack_layout() {
     return P;
 }
 
-// dst[c][r] = src[r*ld + c0 + c]  for r < rows, c < cols   (dst leading dim = rows)
-__global__ void k_transpose(const float* src, int ld, int c0, int rows, int cols, float* dst) {
-    __shared__ float tile[32][33];
-    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-    for (int i = threadIdx.y; i < 32; i += 8) {
-        int r = by + i, c = bx + threadIdx.x;
-        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * ld + c0 + c] : 0.f;
-    }
-    __syncthreads();
-    for (int i = threadIdx.y; i < 32; i += 8) {
-        int c = bx + i, r = by + threadIdx.x;
-        if (r < rows && c < cols) dst[(int64_t)c * rows + r] = tile[threadIdx.x][i];
-    }
-}
 // dst[r][c] = (c < cols) ? src[r*ld + c0 + c] : 0   (dst leading dim = dcols)
 __global__ void k_copy_cols(const float* src, int ld, int c0, int rows, int cols, int dcols, float* dst) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,12 +101,54 @@ __global__ void k_split_planes(const float* src, int64_t n, unsigned short* plan
     planes[2 * n + i] = lb;
 }
 
-static int transpose_into(const float* src, int ld, int c0, int rows, int cols, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, src, ld, c0, rows, cols,
-                       dst);
-    PN_CHECK_LAUNCH();
-    return PN_OK;
+// all weight transposes of one pn_pack_weights call in ONE launch: a workgroup finds its job in a small table
+struct TrJob {
+    const float* src;
+    float* dst;
+    int ld, c0, rows, cols, tile0, tiles_x;
+};
+#define TR_MAXJOBS 12
+struct TrBatch {
+    TrJob j[TR_MAXJOBS];
+    int n;
+};
+// per job: dst[c][r] = src[r*ld + c0 + c]  for r < rows, c < cols   (dst leading dim = rows)
+__global__ void k_transpose_batch(TrBatch tb) {
+    __shared__ float tile[32][33];
+    int k = 0;
+    for (int i = 1; i < tb.n; ++i)
+        if ((int)blockIdx.x >= tb.j[i].tile0) k = i;
+    const TrJob jb = tb.j[k];
+    const int t = blockIdx.x - jb.tile0;
+    const int bx = (t % jb.tiles_x) * 32, by = (t / jb.tiles_x) * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        int r = by + i, c = bx + threadIdx.x;
+        tile[i][threadIdx.x] = (r < jb.rows && c < jb.cols) ? jb.src[(int64_t)r * jb.ld + jb.c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        int c = bx + i, r = by + threadIdx.x;
+        if (r < jb.rows && c < jb.cols) jb.dst[(int64_t)c * jb.rows + r] = tile[threadIdx.x][i];
+    }
 }
+struct TrQueue {
+    TrBatch b;
+    int tiles;
+    TrQueue() : tiles(0) { b.n = 0; }
+    int add(const float* src, int ld, int c0, int rows, int cols, float* dst) {
+        if (b.n >= TR_MAXJOBS) return PN_ERR_BAD_SHAPE;
+        const int tx = (cols + 31) / 32, ty = (rows + 31) / 32;
+        b.j[b.n++] = TrJob{src, dst, ld, c0, rows, cols, tiles, tx};
+        tiles += tx * ty;
+        return PN_OK;
+    }
+    int launch(hipStream_t s) {
+        if (!tiles) return PN_OK;
+        hipLaunchKernelGGL(k_transpose_batch, dim3(tiles), dim3(32, 8), 0, s, b);
+        PN_CHECK_LAUNCH();
+        return PN_OK;
+    }
+};
 
 // -------------------------------------------------------------------------- narrow heads (VALU, HBM-bound)
 // Rows are [K] floats, K = 128 or 256.  A wave covers FOUR rows at a time: 16 lanes per row, each lane owning
@@ -510,18 +538,20 @@ int pn_pack_weights(const float* params, int nc, float* wpack, void* stream) {
     PnLayout L = pn_layout(nc);
     PnPack P = pn_pack_layout();
     hipStream_t s = ST(stream);
+    TrQueue tq;
     for (int l = 0; l < 8; ++l) {
         int k = (l == 0) ? PN_ENC_DIM : (l == 5 ? PN_WIDTH + PN_ENC_DIM : PN_WIDTH);
         int kk = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
-        RUN(transpose_into(params + L.w[l], k, 0, PN_WIDTH, kk, wpack + P.wt[l], s));  // [kk][256]
+        RUN(tq.add(params + L.w[l], k, 0, PN_WIDTH, kk, wpack + P.wt[l]));  // [kk][256]
     }
-    RUN(transpose_into(params + L.w[5], PN_WIDTH + PN_ENC_DIM, PN_WIDTH, PN_WIDTH, PN_ENC_DIM, wpack + P.w5e_t, s));
-    RUN(transpose_into(params + L.we, PN_WIDTH, 0, PN_WIDTH, PN_WIDTH, wpack + P.we_t, s));
+    RUN(tq.add(params + L.w[5], PN_WIDTH + PN_ENC_DIM, PN_WIDTH, PN_WIDTH, PN_ENC_DIM, wpack + P.w5e_t));
+    RUN(tq.add(params + L.we, PN_WIDTH, 0, PN_WIDTH, PN_WIDTH, wpack + P.we_t));
     const int ldv = PN_WIDTH + PN_VIEW_DIM;
+    RUN(tq.add(params + L.wv, ldv, 0, PN_WIDTH_COND, PN_WIDTH, wpack + P.wvm_t));  // [256][128]
+    RUN(tq.launch(s));
     hipLaunchKernelGGL(k_copy_cols, dim3(nblk(PN_WIDTH_COND * PN_WIDTH, 256)), dim3(256), 0, s, params + L.wv, ldv, 0,
                        PN_WIDTH_COND, PN_WIDTH, PN_WIDTH, wpack + P.wvm);
     PN_CHECK_LAUNCH();
-    RUN(transpose_into(params + L.wv, ldv, 0, PN_WIDTH_COND, PN_WIDTH, wpack + P.wvm_t, s));  // [256][128]
     hipLaunchKernelGGL(k_copy_cols, dim3(nblk(PN_WIDTH_COND * 32, 256)), dim3(256), 0, s, params + L.wv, ldv, PN_WIDTH,
                        PN_WIDTH_COND, PN_VIEW_DIM, 32, wpack + P.wvv);
     PN_CHECK_LAUNCH();

@@ -977,6 +977,39 @@ int pn_launch_ipe_tangent(int64_t M, const float* mean, const float* cov, const 
     return PN_OK;
 }
 
+// A training batch out of the HBM-resident ray pool: out_f[b] = pool_f[idx[b]] for the eight Rays fields
+// (3+3+3+1+1+1+1+1 floats) and the target colour (3) in ONE launch (datasets/pano_datasets.py:271-275 does the
+// same gather per __getitem__ on the host).  One thread per output float; an index outside the pool reads ray 0.
+struct GatherTable {
+    const float* src[9];
+    float* dst[9];
+};
+__global__ void k_gather_rays(int64_t B, int64_t pool_rays, const int64_t* idx, GatherTable t) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * 17) return;
+    const int64_t b = e / 17;
+    const int c = (int)(e % 17);
+    // column c of the packed 17-float record -> (field, component)
+    int f, k, w;
+    if (c < 9) {
+        f = c / 3;
+        k = c % 3;
+        w = 3;
+    } else if (c < 14) {
+        f = 3 + (c - 9);
+        k = 0;
+        w = 1;
+    } else {
+        f = 8;
+        k = c - 14;
+        w = 3;
+    }
+    if (!t.src[f]) return;
+    int64_t r = idx[b];
+    r = (r >= 0 && r < pool_rays) ? r : 0;
+    t.dst[f][b * w + k] = t.src[f][r * w + k];
+}
+
 extern "C" {
 
 int pn_raygen_pano(int H, int W, const float* c, float near_, float far_, float* origins, float* directions,
@@ -988,6 +1021,22 @@ int pn_raygen_pano(int H, int W, const float* c, float near_, float far_, float*
     hipLaunchKernelGGL(k_raygen_pano, dim3(nblk((int64_t)H * W, 256)), dim3(256), 0, ST(stream), H, W, c[0], c[1], c[2],
                        c[4], c[5], c[6], c[8], c[9], c[10], c[3], c[7], c[11], near_, far_, origins, directions,
                        viewdirs, radii, lossmult, near_out, far_out, noise_var);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+int pn_gather_rays(int64_t B, int64_t pool_rays, const int64_t* idx, const float* const* pool_host, float* const* out_host,
+                   void* stream) {
+    if (B <= 0 || pool_rays <= 0) return PN_ERR_BAD_SHAPE;
+    if (!idx || !pool_host || !out_host) return PN_ERR_NULL;
+    GatherTable t;
+    for (int f = 0; f < 9; ++f) {
+        t.src[f] = pool_host[f];
+        t.dst[f] = out_host[f];
+        if (f < 8 && (!t.src[f] || !t.dst[f])) return PN_ERR_NULL;       // the eight Rays fields are mandatory
+        if (f == 8 && ((t.src[f] == nullptr) != (t.dst[f] == nullptr))) return PN_ERR_NULL;  // rgb: both or neither
+    }
+    hipLaunchKernelGGL(k_gather_rays, dim3(nblk(B * 17, 256)), dim3(256), 0, ST(stream), B, pool_rays, idx, t);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }

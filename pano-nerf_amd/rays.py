@@ -90,9 +90,17 @@ class DeviceRayPool:
 
     def sample(self, batch_size, generator=None):
         """-> (Rays of [B, C], rgb [B, 3] or None), all on the device."""
-        idx = torch.randint(0, len(self), (int(batch_size),), device=self.rays.origins.device, generator=generator)
-        rays = Rays(*[x[idx] for x in self.rays])
-        return rays, (self.rgbs[idx] if self.rgbs is not None else None)
+        import ctypes
+        dev = self.rays.origins.device
+        B = int(batch_size)
+        idx = torch.randint(0, len(self), (B,), device=dev, generator=generator)
+        outs = [torch.empty(B, x.shape[1], dtype=torch.float32, device=dev) for x in self.rays]
+        rgb = torch.empty(B, 3, dtype=torch.float32, device=dev) if self.rgbs is not None else None
+        src = (ctypes.c_void_p * 9)(*[x.data_ptr() for x in self.rays], self.rgbs.data_ptr() if rgb is not None else None)
+        dst = (ctypes.c_void_p * 9)(*[x.data_ptr() for x in outs], rgb.data_ptr() if rgb is not None else None)
+        with torch.cuda.device(dev):
+            _lib.call("pn_gather_rays", B, len(self), idx.data_ptr(), src, dst, torch.cuda.current_stream(dev).cuda_stream)
+        return Rays(*outs), rgb
 
     def lit_rays(self, num=10, near=0.0, far=10.0):
         return generate_lit_rays(num, self.radius, near, far, device=self.rays.origins.device)

@@ -198,11 +198,31 @@ class _RenderFn(torch.autograd.Function):
         dev = o.device
         B, N, nc = o.shape[0], cfg.num_samples, cfg.nc
         M = B * N
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        # every zero-initialised temporary of this backward is a view of ONE zero-filled arena (one fill launch instead of
+        # ~14; the step is launch-sensitive at 512 rays per GPU); sizes padded to 64 floats keep the views 256-B aligned
+        pad = lambda n: (n + 63) & ~63
+        need = 8 * pad(B * 3) + 2 * pad(B)  # stand-ins for absent upstream gradients
+        if cfg.surf:
+            D_, Ne_ = env_d.shape[0], cfg.num_env_samples
+            need += pad(B * D_ * 3) + 2 * pad(B * 3) + 2 * pad(ee.M * 3) + pad(ee.M * nc)
+        need += 2 * (pad(M * 3) + pad(M * nc)) + pad(B * N) + pad(M * 3)
+        arena = torch.zeros(need, dtype=torch.float32, device=dev)
+        used = [0]
+
+        def z(*shape):
+            n = 1
+            for k in shape:
+                n *= k
+            if used[0] + pad(n) > need:  # not expected; keeps the function total
+                return torch.zeros(*shape, dtype=torch.float32, device=dev)
+            out = arena[used[0]:used[0] + n].view(*shape)
+            used[0] += pad(n)
+            return out
+
         gz = lambda g, *s: _f32(g) if g is not None else z(*s)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            flat_grad = z(params.numel())
+            flat_grad = torch.zeros(params.numel(), dtype=torch.float32, device=dev)  # outlives this call (.grad views)
             pending = []  # (evaluation, its workspace, ran the tangent sweep): weight gradients batched into the last call
             d_dist1 = gz(g_dist1, B).clone()
             d_normal = gz(g_normal, B, 3) if cfg.normals else None

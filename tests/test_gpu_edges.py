@@ -87,6 +87,14 @@ def test_device_ray_pool():
     # a ray's colour comes from the camera its origin belongs to
     cam1 = (rays.origins[:, 0] > 0.05)
     assert torch.allclose(rgb[cam1], torch.full_like(rgb[cam1], 0.75)) and torch.allclose(rgb[~cam1], torch.full_like(rgb[~cam1], 0.25))
+    # the single-launch gather is exactly an index of the pool (same generator -> same indices)
+    g1 = torch.Generator(device="cuda").manual_seed(5)
+    g2 = torch.Generator(device="cuda").manual_seed(5)
+    rays2, rgb2 = pool.sample(97, generator=g1)
+    idx = torch.randint(0, len(pool), (97,), device=dev(), generator=g2)
+    for got, full in zip(rays2, pool.rays):
+        assert torch.equal(got, full[idx])
+    assert torch.equal(rgb2, pool.rgbs[idx])
     env = pool.lit_rays(10)
     assert env.directions.dtype == torch.float16 and env.directions.shape == (10, 3)
     assert abs(float(env.lossmult[0, 0]) - 4 * np.pi / 10) < 2e-3
