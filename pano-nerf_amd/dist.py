@@ -33,6 +33,8 @@ def gather_image(parts, world):
     """Inference: gather per-rank [n_i, C] chunks to every rank (SURVEY.md 8e 'Inference')."""
     if world == 1:
         return parts
+    if parts.is_cuda and dist.get_backend() == "gloo":  # rehearsal on fewer GPUs than ranks: gloo gathers on the host
+        return gather_image(parts.cpu(), world).to(parts.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=parts.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([parts.shape[0]], dtype=torch.int64, device=parts.device))
     mx = int(max(s.item() for s in sizes))

@@ -29,9 +29,12 @@ def render_image(model, rays, env_rays, height, width, chunk_size=32768, white_b
                 use_ort_loss=True)
             for k, v in zip(outs, (c_rgb, f_rgb, c_dep.view(-1, 1), f_dep.view(-1, 1), f_nor, alb, sf_rgb, sd)):
                 outs[k].append(v)
-    cat = {k: torch.cat(v, 0) if v else None for k, v in outs.items()}
+    widths_all = dict(coarse_rgb=3, fine_rgb=3, coarse_dep=1, fine_dep=1, fine_nor=3, albedo=3, surface_rgb=3, shading=3)
+    dev = flat.origins.device
+    # a rank that was dealt no chunk (more ranks than chunks) contributes zero rows
+    cat = {k: torch.cat(v, 0) if v else torch.empty(0, widths_all[k], dtype=torch.float32, device=dev)
+           for k, v in outs.items()}
     if world > 1:
-        import torch.distributed as dist
         from .dist import gather_image
         packed = torch.cat([cat[k] for k in outs], 1)  # [n_local, 20]
         allp = gather_image(packed, world)

@@ -29,3 +29,13 @@ def test_two_rank_bench_flow(graph):
     assert out["config"]["rays_per_gpu"] == 128 and out["value"] > 0
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+
+
+def test_two_rank_render_matches_single_rank():
+    """Sharded full-image inference: chunks dealt round-robin to two ranks, gathered, re-ordered."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "tests", "_render_dist_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert "RENDER_DIST_OK" in res.stdout
