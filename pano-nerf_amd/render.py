@@ -184,7 +184,7 @@ class _RenderFn(torch.autograd.Function):
                 surface = diffuse.clone()
         ctx.cfg, ctx.mlp = cfg, mlp
         ctx.pack = (o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, albedo, normal, params, wpack)
-        if getattr(mlp, "debug_keep", False):  # diagnostics only (tools/diag_full.py)
+        if getattr(mlp, "debug_keep", False):  # diagnostics only (tests/diag/diag_full.py)
             mlp.debug_pack = ctx.pack
         outs = (comp0, dist0, comp1, dist1, ort, normal, albedo, surface, diffuse, shading)
         ctx.present = [x is not None for x in outs]

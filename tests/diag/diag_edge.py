@@ -1,7 +1,8 @@
 """Run one ragged-batch step (B, N from argv) with weight-gradient batching on/off; prints loss and grad norm."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import pano_oracle as orc
 import pano_nerf_amd as pn
 

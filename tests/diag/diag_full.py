@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): where does the level-1 normal deviate?  Compares our intermediates with the
 oracle run in fp32 and fp64 on the same inputs."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
 from conftest import load_golden
