@@ -5,11 +5,12 @@ import numpy as np, torch
 from pano_nerf_amd import _lib as lib
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 M = 524288; K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+FLAGS = int(sys.argv[2], 0) if len(sys.argv) > 2 else 3  # BIAS | RELU; 0x100 adds 'no store'
 A = torch.relu(torch.randn(M, 256, device=dev)); W = torch.randn(256, 256, device=dev) * 0.06
 C = torch.empty(M, 256, device=dev); bias = torch.randn(256, device=dev)
 h = lib.load()
 for _ in range(20):
-    lib.call("pn_gemm_nt", M, 256, K, A.data_ptr(), 256, W.data_ptr(), 256, C.data_ptr(), 256, bias.data_ptr(), None, 256, 3, st)
+    lib.call("pn_gemm_nt", M, 256, K, A.data_ptr(), 256, W.data_ptr(), 256, C.data_ptr(), 256, bias.data_ptr(), None, 256, FLAGS, st)
 torch.cuda.synchronize()
 nb = 8192
 buf = np.zeros(nb * 8, np.uint64)
