@@ -149,51 +149,73 @@ __device__ __forceinline__ void nt_store(float* As, float* Bs, int tid, const Nt
     }
 }
 
-// One row-group step of the shared epilogue: lanes (lane >> 4) pick one of 4 rows, (lane & 15) a float4 of the wave's
-// 64 columns; reads the transposed value from the wave's LDS slab and applies bias / per-ray bias / addend / ReLU /
-// gate / mask bits / mask emission, stores, and adds to the running column sums.
-__device__ __forceinline__ void nt_epi_row(const PnGemmNt& g, const float* Ls, int flags, int lrow, int64_t row, int col4,
-                                           int gcol, bool col_ok, const f32x4& bias4, f32x4& csum, int lane) {
-    const bool ok = col_ok && row < g.M;
-    f32x4 v = *reinterpret_cast<const f32x4*>(Ls + lrow * EPL + col4);
-    v += bias4;
-    if (ok) {
-        if (flags & PN_EPI_ROWBIAS) {
-            int64_t ray = row / g.rows_per_ray;
-            if (g.rb_mod > 0) ray %= g.rb_mod;
-            v += *reinterpret_cast<const f32x4*>(g.rowbias + ray * g.ldrb + gcol);
+// One 32-row slab of the shared epilogue: lanes (lane >> 4) pick one of 4 rows per step, (lane & 15) a float4 of the
+// wave's 64 columns; eight steps read the transposed values from the wave's LDS slab, apply bias / per-ray bias /
+// addend / ReLU / gate / mask bits / mask emission, store, and add to the running column sums.
+// The epilogue's vector instructions only get the issue slots the other workgroups' MFMA streams leave (~25 ns each,
+// profiles/r01_nt_phase_trace_K256.txt), so their COUNT is what matters: F >= 0 fixes the flag set at compile time
+// (the eight sets the MLP uses are instantiated; F < 0 keeps the run-time flags), INTERIOR drops every bounds test
+// for waves whose 64 x 64 block lies inside the matrix, and the row pointers advance by a constant per step.
+template <int F, bool INTERIOR>
+__device__ __forceinline__ void nt_epi_slab(const PnGemmNt& g, const float* Ls, int rtflags, int64_t row0, int col4, int gcol,
+                                            bool col_ok, const f32x4& bias4, f32x4& csum, int lane) {
+    const int flags = F < 0 ? rtflags : F;
+    const int r0 = lane >> 4;
+    int64_t row = row0 + r0;
+    float* cp = g.C + row * g.ldc + gcol;
+    const int64_t cstep = 4 * (int64_t)g.ldc;
+    const float* ap = (flags & PN_EPI_ADDC) ? g.addc + row * g.ldadd + gcol : nullptr;
+    const int64_t astep = 4 * (int64_t)g.ldadd;
+    const uint32_t* bp = (flags & PN_EPI_GATEBITS) ? g.gate_bits + row * PN_MASK_WORDS + (gcol >> 5) : nullptr;
+    uint32_t* mp = (flags & PN_EPI_MASKOUT) ? g.mask_out + row * PN_MASK_WORDS + (gcol >> 5) : nullptr;
+    const int bi = (gcol >> 2) & 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = INTERIOR ? true : (col_ok && row < g.M);
+        f32x4 v = *reinterpret_cast<const f32x4*>(Ls + (r0 + 4 * i) * EPL + col4);
+        if (flags & PN_EPI_BIAS) v += bias4;
+        if (ok) {
+            if (flags & PN_EPI_ROWBIAS) {
+                int64_t ray = row / g.rows_per_ray;
+                if (g.rb_mod > 0) ray %= g.rb_mod;
+                v += *reinterpret_cast<const f32x4*>(g.rowbias + ray * g.ldrb + gcol);
+            }
+            if (flags & PN_EPI_ADDC) v += *reinterpret_cast<const f32x4*>(ap);
         }
-        if (flags & PN_EPI_ADDC) v += *reinterpret_cast<const f32x4*>(g.addc + row * g.ldadd + gcol);
-    }
-    if (flags & PN_EPI_RELU) {
-        v[0] = fmaxf(v[0], 0.f);
-        v[1] = fmaxf(v[1], 0.f);
-        v[2] = fmaxf(v[2], 0.f);
-        v[3] = fmaxf(v[3], 0.f);
-    }
-    if ((flags & PN_EPI_GATE) && ok) {
-        f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + row * g.ldg + gcol);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = gt[c] > 0.f ? v[c] : 0.f;
-    }
-    if ((flags & PN_EPI_GATEBITS) && ok) {
-        uint32_t w = g.gate_bits[row * PN_MASK_WORDS + (gcol >> 5)];
-        const int bi = (gcol >> 2) & 7;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = ((w >> (c * 8 + bi)) & 1u) ? v[c] : 0.f;
-    }
-    if (flags & PN_EPI_MASKOUT) {  // all 64 lanes take part in the ballots
-        uint32_t word = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned long long b = __ballot(v[c] > 0.f);
-            word |= (uint32_t)((b >> ((lane >> 3) * 8)) & 0xffull) << (c * 8);
+        if (flags & PN_EPI_RELU) {
+            v[0] = fmaxf(v[0], 0.f);
+            v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f);
+            v[3] = fmaxf(v[3], 0.f);
         }
-        if (ok && (lane & 7) == 0) g.mask_out[row * PN_MASK_WORDS + (gcol >> 5)] = word;
-    }
-    if (ok) {
-        if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + gcol) = v;
-        csum += v;
+        if ((flags & PN_EPI_GATE) && ok) {
+            f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + row * g.ldg + gcol);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = gt[c] > 0.f ? v[c] : 0.f;
+        }
+        if ((flags & PN_EPI_GATEBITS) && ok) {
+            const uint32_t w = *bp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = ((w >> (c * 8 + bi)) & 1u) ? v[c] : 0.f;
+        }
+        if (flags & PN_EPI_MASKOUT) {  // all 64 lanes take part in the ballots
+            uint32_t word = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned long long b = __ballot(v[c] > 0.f);
+                word |= (uint32_t)((b >> ((lane >> 3) * 8)) & 0xffull) << (c * 8);
+            }
+            if (ok && (lane & 7) == 0) *mp = word;
+        }
+        if (ok) {
+            if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(cp) = v;
+            if (flags & PN_EPI_COLSUM) csum += v;
+        }
+        row += 4;
+        cp += cstep;
+        if (flags & PN_EPI_ADDC) ap += astep;
+        if (flags & PN_EPI_GATEBITS) bp += 4 * PN_MASK_WORDS;
+        if (flags & PN_EPI_MASKOUT) mp += 4 * PN_MASK_WORDS;
     }
 }
 // column sums of one wave's 64 rows -> colsum[(m0 / 64 + wm)][gcol .. gcol + 3]
@@ -230,6 +252,11 @@ __device__ __forceinline__ void nt_epilogue_t(const PnGemmNt& g, f32x16 (&acc)[2
     if ((flags & PN_EPI_BIAS) && col_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + gcol);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();  // every wave is done reading As / Bs
+    // wave-uniform: this wave's 64 x 64 block lies inside the matrix -> no bounds tests in the slab steps
+    const bool interior = (m0 + wm * 64 + 64 <= g.M) && (n0 + wn * 64 + 64 <= g.N);
+    const int known = PN_EPI_BIAS | PN_EPI_ROWBIAS | PN_EPI_ADDC | PN_EPI_RELU | PN_EPI_GATE | PN_EPI_GATEBITS | PN_EPI_MASKOUT |
+                      PN_EPI_COLSUM | 0x100;
+    const int fsel = flags & known;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -241,11 +268,26 @@ __device__ __forceinline__ void nt_epilogue_t(const PnGemmNt& g, f32x16 (&acc)[2
         // needed between the transposed write and the row reads (a __syncthreads() here also carries a fence that
         // waits for the previous slab's global stores).
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int lrow = (lane >> 4) + 4 * i;
-            nt_epi_row(g, Ls, flags, lrow, m0 + wm * 64 + tm * 32 + lrow, col4, gcol, col_ok, bias4, csum, lane);
+        const int64_t row0 = m0 + wm * 64 + tm * 32;
+#define PN_SLAB(FSET)                                                                                             \
+    case (FSET):                                                                                                  \
+        if (interior) nt_epi_slab<(FSET), true>(g, Ls, flags, row0, col4, gcol, col_ok, bias4, csum, lane);        \
+        else nt_epi_slab<(FSET), false>(g, Ls, flags, row0, col4, gcol, col_ok, bias4, csum, lane);                \
+        break;
+        switch (fsel) {  // the flag sets pn_mlp.hip launches with; anything else takes the run-time path
+            PN_SLAB(PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_MASKOUT)
+            PN_SLAB(PN_EPI_ROWBIAS | PN_EPI_RELU | PN_EPI_MASKOUT)
+            PN_SLAB(PN_EPI_BIAS)
+            PN_SLAB(PN_EPI_GATEBITS)
+            PN_SLAB(PN_EPI_GATEBITS | PN_EPI_COLSUM)
+            PN_SLAB(PN_EPI_ADDC | PN_EPI_GATEBITS | PN_EPI_COLSUM)
+            PN_SLAB(PN_EPI_COLSUM)
+            PN_SLAB(0)
+            default:
+                if (interior) nt_epi_slab<-1, true>(g, Ls, flags, row0, col4, gcol, col_ok, bias4, csum, lane);
+                else nt_epi_slab<-1, false>(g, Ls, flags, row0, col4, gcol, col_ok, bias4, csum, lane);
         }
+#undef PN_SLAB
         __builtin_amdgcn_wave_barrier();
     }
     if (flags & PN_EPI_COLSUM) nt_epi_colsum(g, csum, m0, wm, gcol, col_ok, lane);
