@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--cpu-rays", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the full-panorama inference leg (N = 1 only)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
     ap.add_argument("--gemm-mode", choices=("fp32", "split"), default=None,
@@ -327,6 +328,21 @@ def main():
                          "end_to_end_frac": value / world * flop_per_ray_step(args.samples) / (PEAK_F32_MFMA_TFLOPS * 1e12)},
             "psnr_batch_db": psnr, "loss": float(loss),
         }
+        if world == 1 and not args.no_inference:
+            # inference rays/s for one full panorama: the first camera's H x W rays through render_image
+            # (normals + env light + surface shading, 32768-ray chunks), after the timed training region
+            hw = args.height * args.width
+            cam0 = pn.Rays(*[p[:hw] for p in pool])
+            with torch.no_grad():
+                nw = min(32768, hw)
+                pn.render_image(model, pn.Rays(*[p[:nw] for p in cam0]), env, 1, nw, chunk_size=32768)  # warm-up
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                pn.render_image(model, cam0, env, args.height, args.width, chunk_size=32768)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+            out["inference"] = {"pano": f"{args.height}x{args.width}", "num_samples": args.samples, "chunk_size": 32768,
+                                "seconds_per_pano": dt, "rays_per_s": hw / dt}
         if world == 1 and not args.no_cpu_baseline:
             k = args.cpu_rays
             rays_cpu = pn.Rays(*[x[:k].cpu() for x in pn.Rays(*[p[torch.arange(0, k * 997, 997, device=dev) % n_pool]
