@@ -14,7 +14,6 @@ at 4096 rays (BASELINE.json configs[3]/[4]) and split evenly over the ranks: str
 import argparse
 import ctypes
 import json
-import math
 import os
 import sys
 import time

@@ -40,7 +40,7 @@ def render_image(model, rays, env_rays, height, width, chunk_size=32768, white_b
         allp = gather_image(packed, world)
         # undo the round-robin dealing: rank r holds chunks r, r+world, ...
         sizes = [chunks[i].origins.shape[0] for i in range(len(chunks))]
-        order, pos = [], 0
+        pos = 0
         starts = {}
         for r in range(world):
             for i in range(r, len(chunks), world):
