@@ -312,3 +312,32 @@ def test_autocast_call_pattern_is_fp32_inside(golden):
         if a is not None:
             assert b.dtype == torch.float32 and torch.equal(a, b)
     assert torch.equal(l0, l1) and torch.equal(g0, g1)
+
+
+def test_training_is_bit_reproducible():
+    """No atomics anywhere on the path (split-K slabs, bias column sums and head partials are reduced in a fixed
+    order): two runs of the same seeded training steps end with bit-identical parameters."""
+    import numpy as np
+    import pano_nerf_amd as pn
+
+    def run():
+        torch.manual_seed(11)
+        cams = [np.eye(4, dtype=np.float32)]
+        pool = pn.DeviceRayPool(16, 32, cams, images=[np.linspace(0, 1, 16 * 32 * 3, dtype=np.float32).reshape(16, 32, 3)])
+        env = pool.lit_rays(10)
+        model = pn.PanoMipNeRF(num_samples=32, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5).to(dev())
+        model.mlp.load_state_dict(orc.init_params(4, 5))
+        opt = pn.FlatAdam(model.mlp, lr=2e-4)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for i in range(4):
+            rays, gt = pool.sample(192, generator=g)
+            opt.zero_grad()
+            outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+            loss, _ = pn.pano_loss(outs, rays.lossmult, gt)
+            loss.backward()
+            opt.step(model.mlp.last_flat_grad, lr=pn.mip_lr(i))
+        return model.mlp.flat_params().detach().clone(), float(loss.detach())
+
+    p1, l1 = run()
+    p2, l2 = run()
+    assert l1 == l2 and torch.equal(p1, p2)
