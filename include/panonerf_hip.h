@@ -246,10 +246,13 @@ int64_t pn_gemm_tn_work_floats(int64_t M, int N1, int N2);
 int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* Y, int ldy, float* C, int ldc,
                int accumulate, float* work, void* stream);
 
-/* ---- launch timing (bench.py roofline leg; off by default; the one piece of process state) ---
- * While enabled every GEMM launch is bracketed by HIP events on its own stream.  pn_prof_read waits
- * for the recorded events and returns, for kernel class cls (0 = k_gemm_nt, 1 = k_gemm_tn), the summed
- * duration in ms, the launch count and the summed algorithmic FLOPs (2*M*N*K, unpadded). */
+/* ---- launch timing (bench.py roofline leg; off by default) ------------------------------------
+ * pn_prof_enable(on): bit 0 switches the timing on or off; while on, every GEMM launch is bracketed by HIP
+ * events on its own stream.  Bits 8 and up are ABLATION switches for the tools/ micro-benchmarks only (skip
+ * the stores / loads / MFMAs of a GEMM, force a kernel variant); they change results and are never set by
+ * the Python module, the tests or bench.py.  pn_prof_read waits for the recorded events and returns, for
+ * kernel class cls (0 = k_gemm_nt, 1 = k_gemm_tn), the summed duration in ms, the launch count and the
+ * summed algorithmic FLOPs (2*M*N*K, unpadded). */
 /* GEMM arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp32-accurate 3-term bf16 split on
  * v_mfma_f32_32x32x16_bf16 (six partial products per product, fp32 accumulate).  Default 0 unless the environment
  * variable PN_GEMM_MODE=1 is set before the first GEMM. */
