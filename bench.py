@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--gemm-mode", choices=("fp32", "split"), default=None,
                     help="fp32: exact fp32 MFMA (default); split: fp32-accurate 3-term bf16 split on the bf16 matrix cores "
                          "(default follows PN_GEMM_MODE)")
+    ap.add_argument("--streams", default="auto",
+                    help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 2 with <= 1024 "
+                         "rays per GPU (+5 %% at 512 rays: single-wave GEMMs fill each other's bubbles), else 1")
     ap.add_argument("--overlap", choices=("on", "off"), default="off",
                     help="weight-gradient GEMMs on a side stream (on) or in line on the main stream (off)")
     args = ap.parse_args()
@@ -159,13 +162,19 @@ def main():
         """Sample this rank's rays from the HBM pool, render, loss, backward -> (loss, flat gradient)."""
         rays, gt = ray_pool.sample(nb)
         opt.zero_grad()
-        outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+        kw = dict(env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+        if state["streams"] > 1:  # the rank's rays as concurrent sub-batches on separate HIP streams (same gradient)
+            loss, g, outs = pn.concurrent_step(model, pn.pano_loss, rays, gt, parts=state["streams"], **kw)
+            pred = outs[1][0].detach()
+            return loss, pred, gt[:pred.shape[0]], g
+        outs = model(rays=rays, **kw)
         loss, _ = pn.pano_loss(outs, rays.lossmult, gt)
         loss.backward()
         return loss.detach(), outs[1][0].detach(), gt, model.mlp.last_flat_grad
 
     graph = None
-    state = {}
+    n_streams = (2 if nb <= 1024 else 1) if args.streams == "auto" else max(1, int(args.streams))
+    state = {"streams": n_streams}
 
     def step(i, local=False):
         """One training step.  `local=True` (rank-0-only measurement legs after the timed region) skips the gradient
@@ -228,13 +237,16 @@ def main():
     fence()
     _lib.load().pn_prof_enable(1)
     t0 = time.perf_counter()
-    prof_live = graph is None  # HIP events cannot be recorded inside a replayed graph: the roofline leg below runs eagerly
+    # HIP events cannot be recorded inside a replayed graph, and with concurrent sub-batches a launch's wall duration
+    # includes the other chain's share of the matrix cores: in both cases the roofline leg runs right after the region
+    prof_live = graph is None and n_streams == 1
     if not prof_live:
         _lib.load().pn_prof_enable(0)
     for i in range(args.steps):
         loss, pred, gt = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    used_graph = graph is not None
     prof = {}
     for cls, name in ((0, "k_gemm_nt"), (1, "k_gemm_tn")):
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
@@ -243,6 +255,7 @@ def main():
     _lib.load().pn_prof_enable(0)
     if not prof_live:  # graph mode: measure the per-launch figures on 2 eager steps right after the timed region
         eager_graph, graph = graph, None
+        state["streams"] = 1  # one chain: with concurrent sub-batches a launch's wall duration is not its cost
         _lib.load().pn_prof_enable(1)
         for i in range(2):
             step(args.warmup + args.steps + i)
@@ -301,7 +314,9 @@ def main():
                                    f"({hi - lo} per GPU)",
                        "global_batch": args.global_batch, "rays_per_gpu": hi - lo, "num_samples": args.samples,
                        "parallelism": f"dp{world} (rays sharded, one 2.455 MB gradient all-reduce/step)",
-                       "launch": "hip-graph replay" if not prof_live else "eager",
+                       "launch": "hip-graph replay" if used_graph else "eager",
+                       "schedule": (f"{n_streams} concurrent sub-batches of {(hi - lo + n_streams - 1) // n_streams} rays on "
+                                    f"{n_streams} HIP streams per GPU" if n_streams > 1 else "one chain per GPU"),
                        "gemm_mode": "split: x = h + m + l (bf16), six partial products on v_mfma_f32_32x32x16_bf16, fp32 "
                                     "accumulate; weight gradients on fp32 MFMA" if split else "exact fp32 MFMA"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
@@ -310,8 +325,9 @@ def main():
                          "traffic": traffic,
                          "avg_launch_us": avg_us, "launches": n,
                          "measured": "HIP events around every GEMM launch " + ("during the timed region" if prof_live else
-                                     "on 2 eager steps right after the timed region (events cannot be recorded inside a "
-                                     "replayed graph; same kernels, same shapes)"),
+                                     "on 2 eager single-chain steps right after the timed region (events cannot be recorded "
+                                     "inside a replayed graph, and concurrent sub-batches time-share the matrix cores; same "
+                                     "kernels; with sub-batches the timed region's GEMMs have 1/streams of these rows)"),
                          "note": ("timed region runs the weight-gradient GEMMs (k_gemm_tn) on a side stream, concurrently "
                                   "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the "
                                   "same kernels in 2 extra steps with the side stream off.  " if args.overlap == "on" else

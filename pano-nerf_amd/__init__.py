@@ -8,6 +8,7 @@ Public surface (mirrors the reference's names):
     FlatAdam, mip_lr              systems/base_system.py:82-87, utils/lr_schedule.py:51-59
     render_image                  systems/panonerf_system.py:133-192
     metrics, io_exr               utils/metrics.py:210-397 (calc_* / calc_ws_*), utils/io_exr.py:6-47
+    concurrent_step               one training step as concurrent sub-batches on separate HIP streams
 """
 __version__ = "0.1.0"
 
@@ -18,3 +19,4 @@ from .loss import pano_loss, mip_loss  # noqa
 from .optim import FlatAdam, mip_lr  # noqa
 from .renderer import render_image  # noqa
 from . import metrics, io_exr  # noqa
+from .parallel import concurrent_step  # noqa

@@ -265,6 +265,10 @@ class _RenderFn(torch.autograd.Function):
             pending = []
         mlp.last_flat_grad = flat_grad
         ctx.pack = None
+        if getattr(mlp, "defer_param_grads", False):
+            # concurrent_step collects `last_flat_grad` per sub-batch and sets the parameters' .grad once at the end;
+            # handing views to AccumulateGrad here would make autograd synchronise the sub-batch streams
+            return (None,) * (16 + len(list(mlp.named_in_order())))
         return (None,) * 16 + tuple(mlp.grad_views(flat_grad))
 
 

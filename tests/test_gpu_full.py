@@ -341,3 +341,32 @@ def test_training_is_bit_reproducible():
     p1, l1 = run()
     p2, l2 = run()
     assert l1 == l2 and torch.equal(p1, p2)
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_concurrent_sub_batches_give_the_whole_batch_gradient(parts):
+    """pano_nerf_amd.concurrent_step: sub-batches on separate streams, weighted by their share of the rays, reproduce
+    loss and gradient of one call over the whole batch (deterministic sampling, so the only difference is the order
+    of the fp32 sums)."""
+    import pano_nerf_amd as pn
+    B, N = 250, 32  # 250 = 125 + 125 = 84 + 83 + 83: unequal parts for 3
+    flat, rgbs, radius, _ = orc.synthetic_scene(16, 32, 3, seed=4)
+    idx = torch.randint(0, flat.origins.shape[0], (B,), generator=torch.Generator().manual_seed(8))
+    rays = to_dev(pn.Rays(*[x[idx] for x in flat]))
+    gt = rgbs[idx].to(dev())
+    env = pn.generate_lit_rays(10, radius)
+    model = make_pano(N)
+    kw = dict(env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    outs = model(rays=rays, **kw)
+    loss, _ = pn.pano_loss(outs, rays.lossmult, gt)
+    loss.backward()
+    full, full_pgrad = model.mlp.last_flat_grad.clone(), [p.grad.clone() for p in model.mlp.parameters()]
+    for p in model.mlp.parameters():
+        p.grad = None
+    l2, g2, first = pn.concurrent_step(model, pn.pano_loss, rays, gt, parts=parts, **kw)
+    torch.cuda.synchronize()
+    assert abs(float(l2) - float(loss)) < 1e-5 * abs(float(loss))
+    assert float((g2 - full).norm() / full.norm()) < 1e-4
+    for p, ref in zip(model.mlp.parameters(), full_pgrad):
+        assert float((p.grad - ref).norm()) <= 1e-4 * float(ref.norm()) + 1e-12
+    assert first[1][0].shape[0] == (B + parts - 1) // parts
