@@ -1,6 +1,6 @@
-"""Experiment: a 512-ray step as two 256-ray half-batches on two streams (graph-captured), against the single-stream
-step.  The half-batches are independent until the gradient sum, so their single-wave GEMMs can fill each other's
-prologue / epilogue bubbles."""
+"""A training step as 1 / 2 / 4 concurrent sub-batches on as many HIP streams (graph replay), B rays in total
+(argv[1], default 512).  The sub-batches are independent until the gradient sum, so their GEMM chains fill each
+other's first-tile / last-tile bubbles; pano_nerf_amd.concurrent_step is the product form of the 2-stream case."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np, torch
