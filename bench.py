@@ -349,8 +349,8 @@ def main():
             hw = args.height * args.width
             cam0 = pn.Rays(*[p[:hw] for p in pool])
             with torch.no_grad():
-                nw = min(32768, hw)
-                pn.render_image(model, pn.Rays(*[p[:nw] for p in cam0]), env, 1, nw, chunk_size=32768)  # warm-up
+                nw = min(4 * 32768, hw)  # warm-up over four chunks: both chunk streams allocate their buffers once
+                pn.render_image(model, pn.Rays(*[p[:nw] for p in cam0]), env, 1, nw, chunk_size=32768)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 pn.render_image(model, cam0, env, args.height, args.width, chunk_size=32768)
