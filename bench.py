@@ -97,8 +97,9 @@ def main():
                     help="fp32: exact fp32 MFMA (default); split: fp32-accurate 3-term bf16 split on the bf16 matrix cores "
                          "(default follows PN_GEMM_MODE)")
     ap.add_argument("--streams", default="auto",
-                    help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 2 with <= 1024 "
-                         "rays per GPU (+5 %% at 512 rays: single-wave GEMMs fill each other's bubbles), else 1")
+                    help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 2 with <= 2048 "
+                         "rays per GPU (+4 %% at 512..2048 rays: the chains fill each other's bubbles), else 1 (at 4096 rays "
+                         "the gain is 2 %% and one chain keeps the per-launch roofline figures live)")
     ap.add_argument("--overlap", choices=("on", "off"), default="off",
                     help="weight-gradient GEMMs on a side stream (on) or in line on the main stream (off)")
     args = ap.parse_args()
@@ -173,7 +174,7 @@ def main():
         return loss.detach(), outs[1][0].detach(), gt, model.mlp.last_flat_grad
 
     graph = None
-    n_streams = (2 if nb <= 1024 else 1) if args.streams == "auto" else max(1, int(args.streams))
+    n_streams = (2 if nb <= 2048 else 1) if args.streams == "auto" else max(1, int(args.streams))
     state = {"streams": n_streams}
 
     def step(i, local=False):
@@ -220,9 +221,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # graph replay pays when the step is launch-latency sensitive (<= 1024 rays per GPU: +5 %); at 4096 rays per GPU
-    # the 700-node replay is ~1.5 % slower than eager launches, so `auto` keeps those eager
-    use_graph = args.graph == "on" or (args.graph == "auto" and nb <= 1024)
+    # graph replay pays when the step is launch-latency sensitive: +5 % at 512 rays per GPU, +2 % at 2048, +1.3 % at 4096
+    # (measured after the launch-count reductions); `auto` keeps the 4096-ray single-GPU run eager so that its GEMM
+    # launches are timed live with HIP events inside the timed region
+    use_graph = args.graph == "on" or (args.graph == "auto" and nb <= 2048)
     if use_graph:
         try:
             try_capture()
