@@ -47,6 +47,10 @@ SIGNATURES = {
     "pn_gemm_tn_work_floats": ("l", "lii"),
     "pn_gemm_tn": ("i", "liipipipiipp"),
     "pn_set_gemm_mode": ("i", "i"),
+    "pn_chain_pack_bytes": ("l", "i"),
+    "pn_chain_pack": ("i", "piipp"),
+    "pn_chain_acts_floats": ("l", "l"),
+    "pn_chain_forward": ("i", "lilii" + "p" * 9 + "p"),
     "pn_mfma_probe": ("i", "piip"),
     "pn_prof_enable": ("i", "i"),
     "pn_prof_read": ("i", "ippp"),

@@ -1,0 +1,685 @@
+// pn_chain.hip — the radiance MLP as FUSED on-chip chains on the bf16 matrix cores (gfx950).
+//
+// Orientation.  Every layer is computed transposed: H_out^T [features x samples] = W [features x K] * H_in^T
+// [K x samples], with v_mfma_f32_32x32x16_bf16.  A 32x32 accumulator tile then holds one SAMPLE per lane column
+// (lane & 31) and 16 FEATURES in its registers (feature = 32t + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)), which is exactly
+// the B-operand shape of the next layer's MFMA (k runs over the registers): a wave owns 32 samples and carries their
+// activations through the whole chain IN REGISTERS.  No activation ever goes through LDS, nothing is re-read from HBM
+// between layers; activations are written out once (the weight-gradient GEMMs need them) in a sample-minor tiled
+// layout ("T32": [sample block of 32][feature][32 samples], so a register of a wave is two full 128-B lines).
+//
+// Weights are the A operand.  pn_chain_pack lays them out in fragment order (one 1-KB wave fragment per
+// (k-step, feature tile, plane)), cut into uniform chunks that a ring of LDS slots receives by LDS-DMA
+// (global_load_lds_dwordx4), several chunks ahead, across layer and tile boundaries; the four waves of a workgroup (one
+// per SIMD, up to 512 registers each) consume the same chunk for their own 32 samples.
+//
+// Arithmetic.  NP = 3: every fp32 operand is split exactly into three bf16 terms (x = h + m + l) and a product is
+// accumulated in fp32 from its six partial products of weight >= 2^-16 (the error is that of an fp32 fma chain);
+// NP = 1: plain bf16 operands, fp32 accumulate (BASELINE configs[1]).
+//
+// Reference lines replaced: MLP.forward models/pano_mip_nerf.py:95-114 (PureMLP models/mip_nerf.py:81-102),
+// integrated_pos_enc models/mip.py:394-428, pos_enc 431-441, and the autograd / functorch passes through them
+// (vmap(jacrev) models/pano_mip_nerf.py:299-303).
+#include "pn_common.h"
+#include <math.h>
+#include <string.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#define CH_THREADS 256
+#define CH_WAVES 4
+#define HALF_PI_F 1.5707963705062866f
+
+template <int NP>
+struct Cfg {
+    static constexpr int CF = NP == 3 ? 24 : 32;       // fragments (1 KB each) per chunk
+    static constexpr int SLOT = (CF + 1) * 1024;       // + 1 KB of aux floats (bias) per chunk
+    static constexpr int NSLOT = NP == 3 ? 5 : 4;      // ring slots
+    static constexpr int D = NSLOT - 1;                // chunks in flight ahead of the one being consumed
+    static constexpr int SHARE = CF / CH_WAVES + 1;    // DMA instructions per wave and chunk
+    static constexpr int LDS_BYTES = SLOT * NSLOT;
+};
+
+template <int NP>
+struct BFrag {
+    bf16x8 p[NP];
+};
+
+// k index (input feature) of element j of lane half h in k-step ks: the order in which an accumulator tile's
+// registers come out (cdna guide, "an accumulator tile as the next MFMA's operand")
+__host__ __device__ constexpr int kmap(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
+// output feature of accumulator register e of tile t on lane half hh
+__host__ __device__ constexpr int fmap(int t, int e, int hh) { return 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh; }
+
+// ----------------------------------------------------------------------------------------------- chain schedules
+// One entry per GEMM of a chain, in execution order.  KS k-steps of 16, NT feature tiles of 32, CKS k-steps per chunk.
+struct LayerShape {
+    int KS, NT, CKS;
+};
+template <int NP>
+__host__ __device__ constexpr int cks_of(int KS, int NT) {
+    int cap = Cfg<NP>::CF / (NT * NP);
+    int best = 1;
+    for (int c = 1; c <= cap && c <= KS; ++c)
+        if (KS % c == 0) best = c;
+    return best;
+}
+
+enum {  // forward-direction GEMMs
+    F_L0 = 0, F_L1, F_L2, F_L3, F_L4, F_L5, F_L6, F_L7, F_DEN, F_EXTRA, F_VIEW, F_COLOR, F_COUNT
+};
+enum {  // backward-direction GEMMs
+    B_COLOR = 0, B_VIEW, B_EXTRA, B_L7, B_L6, B_L5, B_L4, B_L3, B_L2, B_L1, B_DENC, B_COUNT
+};
+__host__ __device__ constexpr int fwd_ks(int i) {
+    return i == F_L0 ? 6 : i == F_L5 ? 22 : i == F_VIEW ? 18 : i == F_COLOR ? 8 : 16;
+}
+__host__ __device__ constexpr int fwd_nt(int i) { return (i == F_DEN || i == F_COLOR) ? 1 : i == F_VIEW ? 4 : 8; }
+__host__ __device__ constexpr int bwd_ks(int i) { return i == B_COLOR ? 1 : i == B_VIEW ? 8 : i == B_EXTRA ? 17 : i == B_DENC ? 32 : 16; }
+__host__ __device__ constexpr int bwd_nt(int i) { return i == B_COLOR ? 4 : i == B_DENC ? 3 : 8; }
+template <int NP>
+__host__ __device__ constexpr int fwd_chunks(int i) { return fwd_ks(i) / cks_of<NP>(fwd_ks(i), fwd_nt(i)); }
+template <int NP>
+__host__ __device__ constexpr int bwd_chunks(int i) { return bwd_ks(i) / cks_of<NP>(bwd_ks(i), bwd_nt(i)); }
+template <int NP>
+__host__ __device__ constexpr int fwd_chunk0(int i) {
+    int c = 0;
+    for (int k = 0; k < i; ++k) c += fwd_chunks<NP>(k);
+    return c;
+}
+template <int NP>
+__host__ __device__ constexpr int bwd_chunk0(int i) {
+    int c = 0;
+    for (int k = 0; k < i; ++k) c += bwd_chunks<NP>(k);
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------------- packing
+struct PackSeg {
+    int64_t off;     // float offset of the source matrix in the parameter block
+    int ld;          // its leading dimension
+    int k0, kvalid;  // this segment covers k in [k0, k0 + kvalid)
+    int transposed;  // 0: A[i][k] = W[i*ld + col0 + (k-k0)] ; 1: A[i][k] = W[(k-k0)*ld + col0 + i]
+    int col0;
+};
+struct PackLayer {
+    int chunk0, KS, NT, CKS;
+    int rows_valid;
+    int nseg;
+    PackSeg seg[2];
+    int64_t aux_off;  // floats copied to the aux KB of the layer's first chunk (bias); < 0: zeros
+    int aux_n;
+};
+#define PACK_MAXL 16
+struct PackTable {
+    PackLayer L[PACK_MAXL];
+    int n, nchunks;
+};
+
+template <int NP>
+__global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* out) {
+    constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t fi = gid >> 6;  // fragment slot index over all chunks, CF + 1 per chunk (the last is the aux KB)
+    const int chunk = (int)(fi / (CF + 1)), f = (int)(fi % (CF + 1));
+    if (chunk >= tab.nchunks) return;
+    int li = 0;
+    for (int i = 1; i < tab.n; ++i)
+        if (chunk >= tab.L[i].chunk0) li = i;
+    const PackLayer& L = tab.L[li];
+    unsigned char* dst = out + (int64_t)chunk * SLOT + f * 1024 + lane * 16;
+    if (f == CF) {  // aux: 256 floats, 4 per lane
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (chunk == L.chunk0 && L.aux_off >= 0)
+            for (int q = 0; q < 4; ++q)
+                if (lane * 4 + q < L.aux_n) v[q] = params[L.aux_off + lane * 4 + q];
+        memcpy(dst, v, 16);
+        return;
+    }
+    const int kc = chunk - L.chunk0;
+    const int p = f % NP, tt = (f / NP) % L.NT, kk = f / (NP * L.NT);
+    unsigned short o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kk < L.CKS) {
+        const int ks = kc * L.CKS + kk;
+        const int i = 32 * tt + (lane & 31), h = lane >> 5;
+        for (int j = 0; j < 8; ++j) {
+            const int k = kmap(ks, h, j);
+            float x = 0.f;
+            if (i < L.rows_valid)
+                for (int s = 0; s < L.nseg; ++s) {
+                    const PackSeg& sg = L.seg[s];
+                    const int kr = k - sg.k0;
+                    if (kr >= 0 && kr < sg.kvalid)
+                        x = sg.transposed ? params[sg.off + (int64_t)kr * sg.ld + sg.col0 + i]
+                                          : params[sg.off + (int64_t)i * sg.ld + sg.col0 + kr];
+                }
+            const __bf16 hb = (__bf16)x;
+            __bf16 r = hb;
+            if (p >= 1) {
+                const float r1 = x - (float)hb;
+                const __bf16 mb = (__bf16)r1;
+                r = mb;
+                if (p == 2) r = (__bf16)(r1 - (float)mb);
+            }
+            unsigned short bits;
+            __builtin_memcpy(&bits, &r, 2);
+            o[j] = bits;
+        }
+    }
+    memcpy(dst, o, 16);
+}
+
+// ------------------------------------------------------------------------------------------------ the weight ring
+// All four waves issue their share of every chunk's DMA and all four consume every chunk.  acquire(): wait for my
+// share of the oldest chunk in flight, barrier (everyone's share has landed; everyone is done with the chunk
+// consumed before), then refill the slot that chunk just vacated with the chunk D ahead.
+template <int NP>
+struct Ring {
+    const unsigned char* src;  // packed chain (global)
+    unsigned char* lds;
+    uint32_t lds_addr;         // LDS byte address of `lds`
+    int nchunk;  // chunks per pass over the chain
+    int pf, pslot, cslot;
+    int wid, lane;
+    __device__ __forceinline__ void issue() {
+        constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT;
+        const unsigned char* g = src + (int64_t)pf * SLOT + lane * 16;
+        unsigned char* l = lds + pslot * SLOT;
+#pragma unroll
+        for (int i = 0; i < CF / CH_WAVES; ++i) {
+            const int f = wid + CH_WAVES * i;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + f * 1024), (lds_ptr_t)(l + f * 1024), 16, 0, 0);
+        }
+        // the aux KB: every wave moves a quarter (keeps the per-wave DMA count equal: the counted vmcnt relies on it)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (int64_t)pf * SLOT + CF * 1024 + wid * 256 + lane * 4),
+                                         (lds_ptr_t)(l + CF * 1024 + wid * 256), 4, 0, 0);
+        pf = (pf + 1 == nchunk) ? 0 : pf + 1;
+        pslot = (pslot + 1 == Cfg<NP>::NSLOT) ? 0 : pslot + 1;
+    }
+    __device__ __forceinline__ void start(const unsigned char* s, unsigned char* l, int n, int w, int ln, int first) {
+        src = s; lds = l; nchunk = n; wid = w; lane = ln;
+        lds_addr = (uint32_t)(uintptr_t)(lds_ptr_t)l;
+        pf = first; pslot = 0; cslot = 0;
+#pragma unroll
+        for (int i = 0; i < Cfg<NP>::D; ++i) issue();
+    }
+    // returns the LDS byte address of the slot of the next chunk
+    __device__ __forceinline__ uint32_t acquire() {
+        constexpr int N = Cfg<NP>::SHARE * (Cfg<NP>::D - 1);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue();
+        const uint32_t p = lds_addr + cslot * Cfg<NP>::SLOT;
+        cslot = (cslot + 1 == Cfg<NP>::NSLOT) ? 0 : cslot + 1;
+        return p;
+    }
+    __device__ __forceinline__ void drain() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------ the GEMM
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_split(const BFrag<NP>& a, const BFrag<NP>& b, f32x16 v) {
+    if constexpr (NP == 3) {  // small terms first
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
+    } else {
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
+    }
+    return v;
+}
+
+// acc[t] (+)= W-chunks * b[0..KS).  The first chunk's aux KB holds the layer's bias (when BIAS): it initialises the
+// accumulators (register e of tile t <- bias[fmap(t, e, hh)]).  The A fragments of step s + 1 (a step = one
+// (k-step, feature tile) pair, 2 NP MFMAs) are read from LDS before the MFMAs of step s are issued, across chunk
+// boundaries too: the next chunk is acquired while the last fragments of the current one are already in registers.
+// A-fragment reads are inline asm with hand-counted waits: hipcc's own counting turned every other step's wait into
+// lgkmcnt(0), which also waits for the reads just issued for the NEXT step (an LDS latency exposed per two steps).
+template <int NP, int IDX>
+__device__ __forceinline__ void read_a(BFrag<NP>& a, uint32_t addr) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a.p[p]) : "v"(addr), "n"((IDX * NP + p) * 1024) : "memory");
+}
+// all but the newest `LEFT` LDS reads of this wave have returned; ties the fragment registers to the wait
+template <int NP, int LEFT>
+__device__ __forceinline__ void wait_a(BFrag<NP>& a) {
+    if constexpr (NP == 3)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a.p[0]), "+v"(a.p[1]), "+v"(a.p[2]) : "n"(LEFT) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a.p[0]) : "n"(LEFT) : "memory");
+}
+template <int NP, int KS, int NT, int CKS, int KC, int RR>
+struct GemmStep {
+    static __device__ __forceinline__ void run(Ring<NP>& R, const BFrag<NP> (&b)[KS], f32x16 (&acc)[NT], uint32_t& sa,
+                                               BFrag<NP>& a, int lane) {
+        constexpr int PER = CKS * NT, NCH = KS / CKS;
+        constexpr bool in_chunk = RR + 1 < PER, more = in_chunk || (KC + 1 < NCH);
+        BFrag<NP> an;
+        if constexpr (in_chunk) {
+            read_a<NP, RR + 1>(an, sa);
+        } else if constexpr (more) {
+            sa = R.acquire() + lane * 16;
+            read_a<NP, 0>(an, sa);
+        }
+        wait_a<NP, more ? NP : 0>(a);
+        constexpr int ks = KC * CKS + RR / NT, t = RR % NT;
+        acc[t] = mfma_split<NP>(a, b[ks], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) {
+            a = an;
+            GemmStep<NP, KS, NT, CKS, in_chunk ? KC : KC + 1, in_chunk ? RR + 1 : 0>::run(R, b, acc, sa, a, lane);
+        }
+    }
+};
+// acc[t] (+)= W-chunks * b[0..KS).  The first chunk's aux KB holds the layer's bias (when BIAS): it initialises the
+// accumulators (register e of tile t <- bias[fmap(t, e, hh)]).  The A fragments of step s + 1 (a step = one
+// (k-step, feature tile) pair, 2 NP MFMAs) are read from LDS before the MFMAs of step s are issued, across chunk
+// boundaries too: the next chunk is acquired while the last fragments of the current one are already in registers.
+template <int NP, int KS, int NT, bool BIAS, bool ZERO>
+__device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS], f32x16 (&acc)[NT], int lane) {
+    constexpr int CKS = cks_of<NP>(KS, NT);
+    constexpr int CF = Cfg<NP>::CF;
+    const uint32_t s0 = R.acquire();
+    if constexpr (BIAS) {
+        const float* aux = reinterpret_cast<const float*>(R.lds + (s0 - R.lds_addr) + CF * 1024) + 4 * (lane >> 5);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(aux + 32 * t + 8 * g);
+                acc[t][4 * g] = v[0];
+                acc[t][4 * g + 1] = v[1];
+                acc[t][4 * g + 2] = v[2];
+                acc[t][4 * g + 3] = v[3];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not see the asm reads that follow
+    } else if constexpr (ZERO) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    }
+    uint32_t sa = s0 + lane * 16;
+    BFrag<NP> a;
+    read_a<NP, 0>(a, sa);
+    GemmStep<NP, KS, NT, CKS, 0, 0>::run(R, b, acc, sa, a, lane);
+}
+
+// --------------------------------------------------------------------------------------------- register plumbing
+template <int NP>
+__device__ __forceinline__ void split_into(const float (&x)[8], BFrag<NP>& f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        f.p[0][j] = h;
+        if constexpr (NP == 3) {
+            const float r1 = x[j] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            f.p[1][j] = m;
+            f.p[2][j] = (__bf16)(r1 - (float)m);
+        }
+    }
+}
+// accumulator tile t -> k-steps 2t, 2t+1 of the next B operand
+template <int NP>
+__device__ __forceinline__ void acc_to_b(const f32x16& a, BFrag<NP>& b0, BFrag<NP>& b1) {
+    float lo[8], hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = a[j];
+        hi[j] = a[8 + j];
+    }
+    split_into<NP>(lo, b0);
+    split_into<NP>(hi, b1);
+}
+
+// T32 store of one accumulator tile: base points at [block][0][0] + (lane & 31) + 128 * (lane >> 5) floats
+__device__ __forceinline__ void store_tile(float* base, int t, const f32x16& a) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) base[(32 * t + (e & 3) + 8 * (e >> 2)) * 32] = a[e];
+}
+
+// ReLU gate bits of a lane: 4 words; word w covers tiles 2w, 2w+1; bit 16 (t & 1) + e.  Seen from the B operand, the
+// 8 elements of k-step ks of the same lane are byte ks of these 16 bytes.
+__device__ __forceinline__ uint32_t bit_of(float v) {  // v >= 0: 1 if v > 0
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    return u < 1u ? u : 1u;
+}
+template <int NT>
+__device__ __forceinline__ void relu_bits(f32x16 (&acc)[NT], uint32_t (&w)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = 0u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = fmaxf(acc[t][e], 0.f);
+            acc[t][e] = v;
+            w[t >> 1] |= bit_of(v) << (16 * (t & 1) + e);
+        }
+}
+template <int NT>
+__device__ __forceinline__ void gate_bits(f32x16 (&acc)[NT], const uint32_t (&w)[4]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = __builtin_amdgcn_sbfe((int)w[t >> 1], 16 * (t & 1) + e, 1);  // 0 or -1
+            acc[t][e] = __builtin_bit_cast(float, __builtin_bit_cast(int, acc[t][e]) & m);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------- forward chain
+struct FwdArgs {
+    int64_t M, nst;        // sample rows, supertiles of 128
+    int rows_per_ray, nc;
+    int64_t view_rows;
+    const unsigned char* pack;
+    const float* mean;     // [M,3]
+    const float* cov;      // [M,3]
+    const float* viewdirs; // [view_rows,3]
+    float* enc_t;          // T32 [96]
+    float* acts_t;         // T32: h0..h7 [256] x 8, then bottleneck + view encoding [288], then view hidden [128]
+    uint32_t* masks;       // [9][Mp][8]
+    float* raw_rgb;        // [M,3]
+    float* raw_den;        // [M,nc]
+    float dbias_unused;
+};
+__host__ __device__ constexpr int64_t act_off(int slot, int64_t Mp) {  // float offset of activation slot in acts_t
+    return slot <= 8 ? (int64_t)slot * Mp * 256 : 8 * Mp * 256 + Mp * 288;
+}
+__host__ __device__ constexpr int64_t acts_floats(int64_t Mp) { return 8 * Mp * 256 + Mp * 288 + Mp * 128; }
+
+template <int NP>
+__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const int64_t Mp = a.nst * 128;
+    Ring<NP> R;
+    R.start(a.pack, lds, fwd_chunk0<NP>(F_COUNT), wid, lane, 0);
+    for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
+        const int64_t blk = st * 4 + wid;
+        const int64_t row = blk * 32 + c;
+        const int64_t rc = row < a.M ? row : a.M - 1;
+        const int lo = c + 128 * hh;  // lane part of every T32 address
+        // ---- integrated positional encoding -> B operand of layer 0 (and of the skip into layer 5)
+        BFrag<NP> benc[6];
+        {
+            float mu[3], cv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                mu[i] = a.mean[rc * 3 + i];
+                cv[i] = a.cov[rc * 3 + i];
+            }
+            float* et = a.enc_t + blk * (96 * 32) + lo;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {  // k-steps ks (sin half) and ks + 3 (the same features + 48)
+                float xs[8], xc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // feature f = 16 ks + 8 (j >> 2) + (j & 3) + 4 hh: level l = f / 3, channel f % 3
+                    const int f0 = 16 * ks + 8 * (j >> 2) + (j & 3);
+                    const int f = f0 + 4 * hh;
+                    const int l = f / 3, ch = f - 3 * l;
+                    const float sc = (float)(1 << l);
+                    const float m = ch == 0 ? mu[0] : (ch == 1 ? mu[1] : mu[2]);
+                    const float v = ch == 0 ? cv[0] : (ch == 1 ? cv[1] : cv[2]);
+                    const float y = m * sc;
+                    const float e = expf(-0.5f * (v * (sc * sc)));
+                    xs[j] = e * sinf(y);
+                    xc[j] = e * sinf(y + HALF_PI_F);
+                    et[f0 * 32] = xs[j];
+                    et[(48 + f0) * 32] = xc[j];
+                }
+                split_into<NP>(xs, benc[ks]);
+                split_into<NP>(xc, benc[ks + 3]);
+            }
+        }
+        BFrag<NP> bh[16];
+        f32x16 acc[8];
+        uint32_t mw[4];
+        // ---- layer 0
+        chain_gemm<NP, 6, 8, true, false>(R, benc, acc, lane);
+        auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T32 store, next B operand
+            relu_bits<8>(acc, mw);
+            float* ht = a.acts_t + act_off(slot, Mp) + blk * (256 * 32) + lo;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                store_tile(ht, t, acc[t]);
+                acc_to_b<NP>(acc[t], bh[2 * t], bh[2 * t + 1]);
+            }
+            uint32_t* mp = a.masks + ((int64_t)slot * Mp + blk * 32 + c) * 8 + 4 * hh;
+            *reinterpret_cast<uint4*>(mp) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        };
+        finish_hidden(0);
+        // ---- layers 1..4
+#pragma unroll 1
+        for (int l = 1; l <= 4; ++l) {
+            chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
+            finish_hidden(l);
+        }
+        // ---- layer 5: [h4 | enc]
+        {
+            BFrag<NP> b5[22];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) b5[i] = bh[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b5[16 + i] = benc[i];
+            chain_gemm<NP, 22, 8, true, false>(R, b5, acc, lane);
+            finish_hidden(5);
+        }
+#pragma unroll 1
+        for (int l = 6; l <= 7; ++l) {
+            chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
+            finish_hidden(l);
+        }
+        // ---- density head (one tile; channels 0..nc-1 are features 0..nc-1)
+        {
+            f32x16 ad[1];
+            chain_gemm<NP, 16, 1, true, false>(R, bh, ad, lane);
+            if (row < a.M) {
+                if (hh == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < a.nc) a.raw_den[row * a.nc + e] = ad[0][e];
+                } else if (a.nc > 4) {
+                    a.raw_den[row * a.nc + 4] = ad[0][0];
+                }
+            }
+        }
+        // ---- bottleneck (no activation), then the view layer over [bottleneck | view encoding]
+        BFrag<NP> bv[18];
+        {
+            chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
+            float* bt = a.acts_t + act_off(8, Mp) + blk * (288 * 32) + lo;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                store_tile(bt, t, acc[t]);
+                acc_to_b<NP>(acc[t], bv[2 * t], bv[2 * t + 1]);
+            }
+            const int64_t vr = (rc / a.rows_per_ray) % a.view_rows;
+            float vd[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) vd[i] = a.viewdirs[vr * 3 + i];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f0 = 16 * q + 8 * (j >> 2) + (j & 3);
+                    const int v = f0 + 4 * hh;  // view-encoding feature 0..31 (27 real)
+                    float o = 0.f;
+                    if (v < 3) {
+                        o = v == 0 ? vd[0] : (v == 1 ? vd[1] : vd[2]);
+                    } else if (v < PN_VIEW_DIM) {
+                        const int i = v - 3, f = i % 12, half = i / 12, l = f / 3, ch = f % 3;
+                        const float xb = (ch == 0 ? vd[0] : (ch == 1 ? vd[1] : vd[2])) * (float)(1 << l);
+                        o = sinf(half ? xb + HALF_PI_F : xb);
+                    }
+                    x[j] = o;
+                    bt[(256 + f0) * 32] = o;
+                }
+                split_into<NP>(x, bv[16 + q]);
+            }
+        }
+        BFrag<NP> bc[8];
+        {
+            f32x16 av[4];
+            chain_gemm<NP, 18, 4, true, false>(R, bv, av, lane);
+            uint32_t w4[4];
+            relu_bits<4>(av, w4);
+            float* ht = a.acts_t + act_off(9, Mp) + blk * (128 * 32) + lo;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                store_tile(ht, t, av[t]);
+                acc_to_b<NP>(av[t], bc[2 * t], bc[2 * t + 1]);
+            }
+            uint32_t* mp = a.masks + ((int64_t)8 * Mp + blk * 32 + c) * 8 + 4 * hh;
+            *reinterpret_cast<uint4*>(mp) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        {
+            f32x16 ac[1];
+            chain_gemm<NP, 8, 1, true, false>(R, bc, ac, lane);
+            if (row < a.M && hh == 0) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) a.raw_rgb[row * 3 + e] = ac[0][e];
+            }
+        }
+    }
+    R.drain();
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+static void fill_layer(PackLayer& L, int chunk0, int KS, int NT, int CKS, int rows_valid) {
+    L.chunk0 = chunk0; L.KS = KS; L.NT = NT; L.CKS = CKS; L.rows_valid = rows_valid;
+    L.nseg = 0; L.aux_off = -1; L.aux_n = 0;
+}
+static void add_seg(PackLayer& L, int64_t off, int ld, int k0, int kvalid, int transposed, int col0) {
+    L.seg[L.nseg++] = PackSeg{off, ld, k0, kvalid, transposed, col0};
+}
+
+template <int NP>
+static PackTable fwd_table(int nc) {
+    const PnLayout P = pn_layout(nc);
+    PackTable T;
+    T.n = F_COUNT;
+    for (int i = 0; i < F_COUNT; ++i) {
+        PackLayer& L = T.L[i];
+        const int KS = fwd_ks(i), NT = fwd_nt(i);
+        fill_layer(L, fwd_chunk0<NP>(i), KS, NT, cks_of<NP>(KS, NT), 32 * NT);
+        if (i <= F_L7) {
+            const int l = i;
+            const int k = (l == 0) ? PN_ENC_DIM : (l == 5 ? PN_WIDTH + PN_ENC_DIM : PN_WIDTH);
+            add_seg(L, P.w[l], k, 0, k, 0, 0);
+            L.aux_off = P.b[l]; L.aux_n = PN_WIDTH;
+        } else if (i == F_DEN) {
+            L.rows_valid = nc;
+            add_seg(L, P.wd, PN_WIDTH, 0, PN_WIDTH, 0, 0);
+            L.aux_off = P.bd; L.aux_n = nc;
+        } else if (i == F_EXTRA) {
+            add_seg(L, P.we, PN_WIDTH, 0, PN_WIDTH, 0, 0);
+            L.aux_off = P.be; L.aux_n = PN_WIDTH;
+        } else if (i == F_VIEW) {
+            add_seg(L, P.wv, PN_WIDTH + PN_VIEW_DIM, 0, PN_WIDTH + PN_VIEW_DIM, 0, 0);
+            L.aux_off = P.bv; L.aux_n = PN_WIDTH_COND;
+        } else {  // F_COLOR
+            L.rows_valid = 3;
+            add_seg(L, P.wc, PN_WIDTH_COND, 0, PN_WIDTH_COND, 0, 0);
+            L.aux_off = P.bc; L.aux_n = 3;
+        }
+    }
+    T.nchunks = fwd_chunk0<NP>(F_COUNT);
+    return T;
+}
+
+template <int NP>
+static int pack_chain(const PackTable& T, const float* params, unsigned char* out, hipStream_t s) {
+    const int64_t threads = (int64_t)T.nchunks * (Cfg<NP>::CF + 1) * 64;
+    hipLaunchKernelGGL(k_chain_pack<NP>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, T, params, out);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+static int g_chain_cus = 0;
+static int chain_grid(int64_t nst) {
+    if (!g_chain_cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) g_chain_cus = 256;
+        else g_chain_cus = pr.multiProcessorCount;
+    }
+    return (int)(nst < g_chain_cus ? nst : g_chain_cus);
+}
+
+extern "C" {
+
+// bytes of the packed chains for `planes` (3: exact split, 1: plain bf16): [forward chain | backward chain]
+int64_t pn_chain_pack_bytes(int planes) {
+    if (planes == 3) return (int64_t)(fwd_chunk0<3>(F_COUNT) + bwd_chunk0<3>(B_COUNT)) * Cfg<3>::SLOT;
+    if (planes == 1) return (int64_t)(fwd_chunk0<1>(F_COUNT) + bwd_chunk0<1>(B_COUNT)) * Cfg<1>::SLOT;
+    return PN_ERR_UNSUPPORTED;
+}
+
+int pn_chain_pack(const float* params, int nc, int planes, void* pack, void* stream) {
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (!params || !pack) return PN_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* out = (unsigned char*)pack;
+    if (planes == 3) return pack_chain<3>(fwd_table<3>(nc), params, out, s);
+    if (planes == 1) return pack_chain<1>(fwd_table<1>(nc), params, out, s);
+    return PN_ERR_UNSUPPORTED;
+}
+
+int64_t pn_chain_acts_floats(int64_t M) { return acts_floats(pn_pad(M)); }
+
+int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int planes, const void* pack,
+                     const float* mean, const float* cov, const float* viewdirs, float* enc_t, float* acts_t,
+                     uint32_t* masks, float* raw_rgb, float* raw_den, void* stream) {
+    if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (!pack || !mean || !cov || !viewdirs || !enc_t || !acts_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;
+    FwdArgs a{};
+    a.M = M;
+    a.nst = pn_pad(M) / 128;
+    a.rows_per_ray = rows_per_ray;
+    a.nc = nc;
+    a.view_rows = view_rows;
+    a.pack = (const unsigned char*)pack;
+    a.mean = mean; a.cov = cov; a.viewdirs = viewdirs;
+    a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = chain_grid(a.nst);
+    if (planes == 3) {
+        static bool attr3 = false;
+        if (!attr3) {
+            if (hipFuncSetAttribute((const void*)k_chain_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<3>::LDS_BYTES) != hipSuccess) return PN_ERR_HIP;
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(k_chain_fwd<3>, dim3(grid), dim3(CH_THREADS), Cfg<3>::LDS_BYTES, s, a);
+    } else if (planes == 1) {
+        static bool attr1 = false;
+        if (!attr1) {
+            if (hipFuncSetAttribute((const void*)k_chain_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<1>::LDS_BYTES) != hipSuccess) return PN_ERR_HIP;
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(k_chain_fwd<1>, dim3(grid), dim3(CH_THREADS), Cfg<1>::LDS_BYTES, s, a);
+    } else {
+        return PN_ERR_UNSUPPORTED;
+    }
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""GPU check of the fused forward chain (pn_chain_forward) against the layer-wise exact-fp32 path (pn_mlp_forward)."""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from pano_nerf_amd import _lib
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+st = lambda: torch.cuda.current_stream().cuda_stream
+E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+
+
+def t32_to_rows(t, Mp, F):
+    return t.view(Mp // 32, F, 32).permute(0, 2, 1).reshape(Mp, F)
+
+
+def run(M, rows_per_ray, planes, nc=5, reps=0):
+    torch.manual_seed(0)
+    import ctypes
+    off = (ctypes.c_int64 * 24)()
+    total = lib.pn_param_layout(nc, off)
+    params = (torch.rand(total, device=dev) - 0.5) * 0.2
+    R = M // rows_per_ray
+    mean = (torch.rand(M, 3, device=dev) - 0.5) * 6
+    cov = torch.rand(M, 3, device=dev) * 1e-4
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
+    Mp = int(lib.pn_pad_rows(M))
+    # reference: layer-wise fp32 MFMA
+    wpack = E(int(lib.pn_wpack_floats(nc)))
+    _lib.call("pn_pack_weights", params.data_ptr(), nc, wpack.data_ptr(), st())
+    enc, venc, vb = E(Mp, 96), E(R, 27), E(R, 128)
+    acts = E(10, Mp, 256)
+    masks = torch.empty(9, Mp, 8, dtype=torch.int32, device=dev)
+    rr, rd = E(M, 3), E(M, nc)
+    _lib.call("pn_mlp_forward", M, rows_per_ray, R, nc, params.data_ptr(), wpack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
+              vd.data_ptr(), enc.data_ptr(), venc.data_ptr(), vb.data_ptr(), acts.data_ptr(), masks.data_ptr(), rr.data_ptr(),
+              rd.data_ptr(), st())
+    # fused chain
+    pack = torch.empty(int(lib.pn_chain_pack_bytes(planes)), dtype=torch.uint8, device=dev)
+    _lib.call("pn_chain_pack", params.data_ptr(), nc, planes, pack.data_ptr(), st())
+    enc_t = E(Mp * 96)
+    acts_t = E(int(lib.pn_chain_acts_floats(M)))
+    masks_f = torch.zeros(9, Mp, 8, dtype=torch.int32, device=dev)
+    rr2, rd2 = E(M, 3), E(M, nc)
+    call = lambda: _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
+                             vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(),
+                             rd2.data_ptr(), st())
+    call()
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    print(f"M={M} planes={planes}")
+    print("  enc      ", rel(t32_to_rows(enc_t, Mp, 96)[:M], enc[:M]))
+    for l in range(8):
+        h = t32_to_rows(acts_t[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
+        print(f"  h{l}       ", rel(h, acts[l, :M]))
+    b = t32_to_rows(acts_t[8 * Mp * 256:8 * Mp * 256 + Mp * 288], Mp, 288)[:M]
+    print("  bott     ", rel(b[:, :256], acts[8, :M]))
+    vr = (torch.arange(M, device=dev) // rows_per_ray) % R
+    print("  viewenc  ", rel(b[:, 256:283], venc[vr]), float(b[:, 283:].abs().max()))
+    hv = t32_to_rows(acts_t[8 * Mp * 256 + Mp * 288:], Mp, 128)[:M]
+    print("  hv       ", rel(hv, acts[9, :M, :128]))
+    print("  raw_rgb  ", rel(rr2, rr), " raw_den", rel(rd2, rd))
+    # gate bits: word w of half hh covers tiles 2w, 2w+1, bit 16 (t & 1) + e <-> feature 32 t + (e & 3) + 8 (e >> 2) + 4 hh
+    mf = masks_f.view(9, Mp, 2, 4)
+    bad = 0
+    for l in (0, 5, 7):
+        h = t32_to_rows(acts_t[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
+        for hh in range(2):
+            for t in (0, 3, 7):
+                for e in (0, 5, 15):
+                    f = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh
+                    bit = (mf[l, :M, hh, t >> 1] >> (16 * (t & 1) + e)) & 1
+                    bad += int((bit.bool() != (h[:, f] > 0)).sum())
+    print("  gate-bit mismatches (sampled):", bad)
+    if reps:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        flops = M * 2 * 611328.0 * (6 if planes == 3 else 1)
+        print(f"  fused forward {dt*1e3:.3f} ms  ({M*2*611328.0/dt/1e12:.1f} TF fp32-equivalent, {flops/dt/1e12:.0f} TF bf16 issued)")
+        ref = lambda: _lib.call("pn_mlp_forward", M, rows_per_ray, R, nc, params.data_ptr(), wpack.data_ptr(), mean.data_ptr(),
+                                cov.data_ptr(), vd.data_ptr(), enc.data_ptr(), venc.data_ptr(), vb.data_ptr(), acts.data_ptr(),
+                                masks.data_ptr(), rr.data_ptr(), rd.data_ptr(), st())
+        ref(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ref()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        print(f"  layer-wise fp32 forward {dt*1e3:.3f} ms ({M*2*611328.0/dt/1e12:.1f} TF)")
+
+
+if __name__ == "__main__":
+    run(64 * 32, 32, 3)
+    run(16 * 128 + 0, 128, 1)
+    run(1000 * 10, 10, 3)
+    run(4096 * 128, 128, 3, reps=5)
+    run(4096 * 128, 128, 1, reps=5)
