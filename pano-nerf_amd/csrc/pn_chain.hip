@@ -375,9 +375,23 @@ __device__ __forceinline__ void gate_bits(f32x16 (&acc)[NT], const uint32_t (&w)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = __builtin_amdgcn_sbfe((int)w[t >> 1], 16 * (t & 1) + e, 1);  // 0 or -1
-            acc[t][e] = __builtin_bit_cast(float, __builtin_bit_cast(int, acc[t][e]) & m);
+            const float x = acc[t][e];  // (a bit_cast applied directly to the vector element reads element 0)
+            acc[t][e] = __int_as_float(__float_as_int(x) & m);
         }
 }
+
+#ifdef PN_TRACE_CHAIN  // debug build only (PN_EXTRA=-DPN_TRACE_CHAIN): shader-clock stamps of one wave's second tile
+__device__ unsigned long long g_chain_trace[64];
+extern "C" int pn_chain_trace_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
+}
+#define TR(i)                                                                                          \
+    do {                                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && st == (int64_t)gridDim.x) g_chain_trace[i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TR(i)
+#endif
 
 // ------------------------------------------------------------------------------------------------- forward chain
 struct FwdArgs {
@@ -414,6 +428,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
         const int64_t row = blk * 32 + c;
         const int64_t rc = row < a.M ? row : a.M - 1;
         const int lo = c + 128 * hh;  // lane part of every T32 address
+        TR(0);
         // ---- integrated positional encoding -> B operand of layer 0 (and of the skip into layer 5)
         BFrag<NP> benc[6];
         {
@@ -451,7 +466,9 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
         f32x16 acc[8];
         uint32_t mw[4];
         // ---- layer 0
+        TR(1);
         chain_gemm<NP, 6, 8, true, false>(R, benc, acc, lane);
+        TR(2);
         auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T32 store, next B operand
             relu_bits<8>(acc, mw);
             float* ht = a.acts_t + act_off(slot, Mp) + blk * (256 * 32) + lo;
@@ -464,11 +481,14 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
             *reinterpret_cast<uint4*>(mp) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
         };
         finish_hidden(0);
+        TR(3);
         // ---- layers 1..4
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
+            TR(2 + 2 * l);
             finish_hidden(l);
+            TR(3 + 2 * l);
         }
         // ---- layer 5: [h4 | enc]
         {
@@ -478,12 +498,16 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) b5[16 + i] = benc[i];
             chain_gemm<NP, 22, 8, true, false>(R, b5, acc, lane);
+            TR(12);
             finish_hidden(5);
+            TR(13);
         }
 #pragma unroll 1
         for (int l = 6; l <= 7; ++l) {
             chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
+            TR(2 + 2 * l);
             finish_hidden(l);
+            TR(3 + 2 * l);
         }
         // ---- density head (one tile; channels 0..nc-1 are features 0..nc-1)
         {
@@ -499,10 +523,12 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
                 }
             }
         }
+        TR(18);
         // ---- bottleneck (no activation), then the view layer over [bottleneck | view encoding]
         BFrag<NP> bv[18];
         {
             chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
+            TR(19);
             float* bt = a.acts_t + act_off(8, Mp) + blk * (288 * 32) + lo;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -534,10 +560,12 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
                 split_into<NP>(x, bv[16 + q]);
             }
         }
+        TR(20);
         BFrag<NP> bc[8];
         {
             f32x16 av[4];
             chain_gemm<NP, 18, 4, true, false>(R, bv, av, lane);
+            TR(21);
             uint32_t w4[4];
             relu_bits<4>(av, w4);
             float* ht = a.acts_t + act_off(9, Mp) + blk * (128 * 32) + lo;
@@ -549,12 +577,397 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
             uint32_t* mp = a.masks + ((int64_t)8 * Mp + blk * 32 + c) * 8 + 4 * hh;
             *reinterpret_cast<uint4*>(mp) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
+        TR(22);
         {
             f32x16 ac[1];
             chain_gemm<NP, 8, 1, true, false>(R, bc, ac, lane);
+            TR(23);
             if (row < a.M && hh == 0) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e) a.raw_rgb[row * 3 + e] = ac[0][e];
+            }
+        }
+        TR(24);
+    }
+    R.drain();
+}
+
+
+// ---------------------------------------------------------------------------------- shared pieces of the sweeps
+__device__ __forceinline__ float ch_sp_d1(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float ch_sp_d2(float x) {
+    if (x > 20.f) return 0.f;
+    const float s = 1.f / (1.f + expf(-x));
+    return s * (1.f - s);
+}
+__device__ __forceinline__ float sel3(const float (&v)[3], int ch) { return ch == 0 ? v[0] : (ch == 1 ? v[1] : v[2]); }
+
+// The gate words of a tile's layers are loaded once, in the order the chain uses them, and consumed from the front:
+// static indices only (a run-time index puts the array in scratch memory).
+template <int N>
+__device__ __forceinline__ uint4 pop_front(uint4 (&q)[N]) {
+    const uint4 m = q[0];
+#pragma unroll
+    for (int i = 0; i + 1 < N; ++i) q[i] = q[i + 1];
+    return m;
+}
+// gate, T32 store and next B operand of a 256-wide hidden vector (backward-direction sweeps and the tangent sweep)
+template <int NP>
+__device__ __forceinline__ void finish_gated(f32x16 (&acc)[8], const uint4& m, float* out, BFrag<NP> (&bh)[16]) {
+    const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+    gate_bits<8>(acc, w);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) store_tile(out, t, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc_to_b<NP>(acc[t], bh[2 * t], bh[2 * t + 1]);
+}
+// B operand k-steps [0, 16) <- a stored T32 [256] block of this wave (fp32), e.g. r5 / delta5 for the skip columns
+template <int NP>
+__device__ __forceinline__ void reload_b(const float* src, int hh, BFrag<NP> (&b)[16]) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = src[(16 * ks + 8 * (j >> 2) + (j & 3)) * 32];  // + 4 hh rows via the lane offset
+        split_into<NP>(x, b[ks]);
+    }
+}
+// d enc (three accumulator tiles: 96 features) -> d mean of this lane's sample; both lane halves end with the sum
+__device__ __forceinline__ void ipe_backward_tiles(const f32x16 (&acc)[3], const float (&mu)[3], const float (&cv)[3], int hh,
+                                                   float (&dm)[3]) {
+    dm[0] = dm[1] = dm[2] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int F0 = 32 * t + (e & 3) + 8 * (e >> 2);  // + 4 hh
+            const int F = F0 + 4 * hh;
+            const bool cosine = F >= 48;
+            const int f = cosine ? F - 48 : F;
+            const int l = f / 3, ch = f - 3 * l;
+            const float sc = (float)(1 << l);
+            const float y = sel3(mu, ch) * sc;
+            const float ex = expf(-0.5f * (sel3(cv, ch) * (sc * sc))) * sc;
+            const float g = acc[t][e] * ex * cosf(cosine ? y + HALF_PI_F : y);
+            dm[0] += ch == 0 ? g : 0.f;
+            dm[1] += ch == 1 ? g : 0.f;
+            dm[2] += ch == 2 ? g : 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dm[i] += __shfl_xor(dm[i], 32, 64);
+}
+
+// ------------------------------------------------------------------------- density-gradient reverse sweep (level 1)
+// r_7 = softplus'(z) * Wd[0] * gate_7 ; r_{l-1} = gate_{l-1} * (W_l[:, :256]^T r_l) ; d sigma / d enc = W_0^T r_0 +
+// W_5[:, 256:]^T r_5 ; grad_mean = IPE^T (d sigma / d enc).  Replaces vmap(jacrev(compute_graph))[1]
+// (models/pano_mip_nerf.py:299-303): one reverse sweep instead of the 8-output Jacobian.
+struct SweepArgs {
+    int64_t M, nst;
+    int nc;
+    float density_bias;
+    const unsigned char* pack;   // first chunk of the sub-chain this kernel walks
+    int nchunk;
+    const uint32_t* masks;       // [9][Mp][8]
+    const float* raw_den;        // [M,nc]
+    const float* mean;
+    const float* cov;
+    const float* wd0;            // density_layer.weight[0] (256 floats, in the parameter block)
+    const float* v;              // [M,3] tangent direction (tangent sweep)
+    float* vec_t;                // T32 [8][256]: r_0..r_7 (reverse sweep) or hdot_0..hdot_7 (tangent sweep)
+    float* edot_t;               // T32 [96] (tangent sweep)
+    float* out3;                 // [M,3] grad_mean (reverse sweep)
+    float* sdot;                 // [M] (tangent sweep)
+};
+
+template <int NP>
+__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_dgrad(SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const int64_t Mp = a.nst * 128;
+    Ring<NP> R;
+    R.start(a.pack, lds, a.nchunk, wid, lane, 0);
+    for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
+        const int64_t blk = st * 4 + wid;
+        const int64_t row = blk * 32 + c;
+        const int64_t rc = row < a.M ? row : a.M - 1;
+        const int lo = c + 128 * hh;
+        uint4 mk[8];  // gates of h7, h6, ..., h0
+#pragma unroll
+        for (int l = 0; l < 8; ++l) mk[l] = *reinterpret_cast<const uint4*>(a.masks + ((int64_t)(7 - l) * Mp + blk * 32 + c) * 8 + 4 * hh);
+        float mu[3], cv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            mu[i] = a.mean[rc * 3 + i];
+            cv[i] = a.cov[rc * 3 + i];
+        }
+        const float sgm = row < a.M ? ch_sp_d1(a.raw_den[rc * a.nc] + a.density_bias) : 0.f;
+        BFrag<NP> bh[16];
+        {  // seed r_7
+            float* rt = a.vec_t + (int64_t)7 * Mp * 256 + blk * (256 * 32) + lo;
+            const uint4 m7 = pop_front(mk);
+            const uint32_t w[4] = {m7.x, m7.y, m7.z, m7.w};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                float x[8];
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.wd0 + 16 * ks + 4 * hh);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.wd0 + 16 * ks + 8 + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float wv = j < 4 ? w0[j & 3] : w1[j & 3];
+                    const uint32_t bit = (w[ks >> 2] >> (8 * (ks & 3) + j)) & 1u;
+                    x[j] = bit ? sgm * wv : 0.f;
+                    rt[(16 * ks + 8 * (j >> 2) + (j & 3)) * 32] = x[j];
+                }
+                split_into<NP>(x, bh[ks]);
+            }
+        }
+        f32x16 acc[8];
+#pragma unroll 1
+        for (int l = 7; l >= 1; --l) {
+            chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)(l - 1) * Mp * 256 + blk * (256 * 32) + lo, bh);
+        }
+        {  // d sigma / d enc over [r_0 | r_5], then the encoding's adjoint
+            static_assert(cks_of<NP>(16, 3) == cks_of<NP>(32, 3), "the two halves walk the chunks of one K = 512 GEMM");
+            f32x16 a3[3];
+            chain_gemm<NP, 16, 3, false, true>(R, bh, a3, lane);
+            reload_b<NP>(a.vec_t + (int64_t)5 * Mp * 256 + blk * (256 * 32) + lo, hh, bh);
+            chain_gemm<NP, 16, 3, false, false>(R, bh, a3, lane);
+            float dm[3];
+            ipe_backward_tiles(a3, mu, cv, hh, dm);
+            if (row < a.M && hh == 0) {
+                a.out3[row * 3] = dm[0];
+                a.out3[row * 3 + 1] = dm[1];
+                a.out3[row * 3 + 2] = dm[2];
+            }
+        }
+    }
+    R.drain();
+}
+
+// ------------------------------------------------------------------------------------- tangent sweep (level 1)
+// hdot_l = gate_l * (W_l hdot_{l-1}) from edot = d enc / d mean . v ; sdot = Wd[0] . hdot_7.  With the saved r_l this gives
+// the second-order weight gradients dW_l += r_l^T hdot_{l-1} (the double backward of models/pano_mip_nerf.py:299-313).
+template <int NP>
+__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_tangent(SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const int64_t Mp = a.nst * 128;
+    Ring<NP> R;
+    R.start(a.pack, lds, a.nchunk, wid, lane, 0);
+    for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
+        const int64_t blk = st * 4 + wid;
+        const int64_t row = blk * 32 + c;
+        const int64_t rc = row < a.M ? row : a.M - 1;
+        const int lo = c + 128 * hh;
+        uint4 mk[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) mk[l] = *reinterpret_cast<const uint4*>(a.masks + ((int64_t)l * Mp + blk * 32 + c) * 8 + 4 * hh);
+        float mu[3], cv[3], vv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            mu[i] = a.mean[rc * 3 + i];
+            cv[i] = a.cov[rc * 3 + i];
+            vv[i] = row < a.M ? a.v[rc * 3 + i] : 0.f;
+        }
+        BFrag<NP> benc[6];
+        {
+            float* et = a.edot_t + blk * (96 * 32) + lo;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                float xs[8], xc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f0 = 16 * ks + 8 * (j >> 2) + (j & 3);
+                    const int f = f0 + 4 * hh;
+                    const int l = f / 3, ch = f - 3 * l;
+                    const float sc = (float)(1 << l);
+                    const float y = sel3(mu, ch) * sc;
+                    const float e = expf(-0.5f * (sel3(cv, ch) * (sc * sc))) * sc * sel3(vv, ch);
+                    xs[j] = e * cosf(y);
+                    xc[j] = e * cosf(y + HALF_PI_F);
+                    et[f0 * 32] = xs[j];
+                    et[(48 + f0) * 32] = xc[j];
+                }
+                split_into<NP>(xs, benc[ks]);
+                split_into<NP>(xc, benc[ks + 3]);
+            }
+        }
+        BFrag<NP> bh[16];
+        f32x16 acc[8];
+        chain_gemm<NP, 6, 8, false, true>(R, benc, acc, lane);
+        finish_gated<NP>(acc, pop_front(mk), a.vec_t + blk * (256 * 32) + lo, bh);
+#pragma unroll 1
+        for (int l = 1; l <= 4; ++l) {
+            chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)l * Mp * 256 + blk * (256 * 32) + lo, bh);
+        }
+        {
+            BFrag<NP> b5[22];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) b5[i] = bh[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b5[16 + i] = benc[i];
+            chain_gemm<NP, 22, 8, false, true>(R, b5, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)5 * Mp * 256 + blk * (256 * 32) + lo, bh);
+        }
+        chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
+        finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)6 * Mp * 256 + blk * (256 * 32) + lo, bh);
+        chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
+        {
+            const uint4 m7 = pop_front(mk);
+            const uint32_t w[4] = {m7.x, m7.y, m7.z, m7.w};
+            gate_bits<8>(acc, w);
+            float* ht = a.vec_t + (int64_t)7 * Mp * 256 + blk * (256 * 32) + lo;
+            float sd = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                store_tile(ht, t, acc[t]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.wd0 + 32 * t + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sd += acc[t][4 * g + i] * wv[i];
+                }
+            }
+            sd += __shfl_xor(sd, 32, 64);
+            if (row < a.M && hh == 0) a.sdot[row] = sd;
+        }
+    }
+    R.drain();
+}
+
+// ------------------------------------------------------------------------------------------------- backward chain
+// d raw_rgb, d raw_density -> delta of every layer (T32, for the weight-gradient GEMMs) -> optionally d mean.
+struct BwdArgs {
+    int64_t M, nst;
+    int nc;
+    float density_bias;
+    const unsigned char* pack;  // backward chain
+    int nchunk;                 // chunks walked per tile (with or without the d enc GEMM)
+    const uint32_t* masks;
+    const float* raw_den;       // [M,nc]
+    const float* d_rgb;         // [M,3]
+    const float* d_den;         // [M,nc]
+    const float* sdot;          // [M] or null: second-order addend softplus''(z) * sdot on channel 0
+    const float* mean;
+    const float* cov;
+    float* drgb_t;              // T32 [32]
+    float* dhv_t;               // T32 [128]
+    float* d8_t;                // T32 [288]: d bottleneck | d raw_density (padded)
+    float* delta_t;             // T32 [8][256]
+    float* coef_t;              // T32 [32] or null: row 0 = softplus'(z) (second-order dWd[0] term)
+    float* d_mean;              // [M,3] or null
+};
+
+template <int NP>
+__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_bwd(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const int64_t Mp = a.nst * 128;
+    Ring<NP> R;
+    R.start(a.pack, lds, a.nchunk, wid, lane, 0);
+    for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
+        const int64_t blk = st * 4 + wid;
+        const int64_t row = blk * 32 + c;
+        const bool live = row < a.M;
+        const int64_t rc = live ? row : a.M - 1;
+        const int lo = c + 128 * hh;
+        uint4 mk[9];  // gates of the view hidden, h7, h6, ..., h0
+#pragma unroll
+        for (int l = 0; l < 9; ++l) mk[l] = *reinterpret_cast<const uint4*>(a.masks + ((int64_t)(8 - l) * Mp + blk * 32 + c) * 8 + 4 * hh);
+        // ---- colour head: d hv = gate * (Wc^T d rgb)
+        BFrag<NP> b1[1];
+        {
+            float x[8];
+            float* dt = a.drgb_t + blk * (32 * 32) + lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f0 = 8 * (j >> 2) + (j & 3);  // feature f0 + 4 hh of the 16 this k-step holds
+                x[j] = (live && hh == 0 && f0 < 3) ? a.d_rgb[rc * 3 + (f0 < 3 ? f0 : 0)] : 0.f;
+                dt[f0 * 32] = x[j];
+            }
+            split_into<NP>(x, b1[0]);
+        }
+        BFrag<NP> bc[8];
+        {
+            f32x16 av[4];
+            chain_gemm<NP, 1, 4, false, true>(R, b1, av, lane);
+            const uint4 m8 = pop_front(mk);
+            const uint32_t w[4] = {m8.x, m8.y, m8.z, m8.w};
+            gate_bits<4>(av, w);
+            float* ht = a.dhv_t + blk * (128 * 32) + lo;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                store_tile(ht, t, av[t]);
+                acc_to_b<NP>(av[t], bc[2 * t], bc[2 * t + 1]);
+            }
+        }
+        // ---- view layer: d bottleneck = Wv[:, :256]^T d hv ; then [d bottleneck | d raw_density] through [We ; Wd]^T
+        BFrag<NP> be[17];
+        f32x16 acc[8];
+        {
+            chain_gemm<NP, 8, 8, false, true>(R, bc, acc, lane);
+            float* bt = a.d8_t + blk * (288 * 32) + lo;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                store_tile(bt, t, acc[t]);
+                acc_to_b<NP>(acc[t], be[2 * t], be[2 * t + 1]);
+            }
+            const float z = a.raw_den[rc * a.nc] + a.density_bias;
+            const float add0 = (a.sdot && live) ? ch_sp_d2(z) * a.sdot[rc] : 0.f;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f0 = 8 * (j >> 2) + (j & 3);
+                const int ch = f0 + 4 * hh;
+                float v = 0.f;
+                if (live && ch < a.nc) v = a.d_den[rc * a.nc + ch] + (ch == 0 ? add0 : 0.f);
+                x[j] = v;
+                bt[(256 + f0) * 32] = v;
+            }
+            split_into<NP>(x, be[16]);
+            if (a.coef_t) {
+                float* ct = a.coef_t + blk * (32 * 32) + lo;
+                const float cf = live ? ch_sp_d1(z) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f0 = 8 * (j >> 2) + (j & 3);
+                    ct[f0 * 32] = (f0 == 0 && hh == 0) ? cf : 0.f;
+                }
+            }
+        }
+        BFrag<NP> bh[16];
+        chain_gemm<NP, 17, 8, false, true>(R, be, acc, lane);
+        finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)7 * Mp * 256 + blk * (256 * 32) + lo, bh);
+#pragma unroll 1
+        for (int l = 7; l >= 1; --l) {
+            chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)(l - 1) * Mp * 256 + blk * (256 * 32) + lo, bh);
+        }
+        if (a.d_mean) {  // uniform: d enc over [delta_0 | delta_5], then the encoding's adjoint
+            float mu[3], cv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                mu[i] = a.mean[rc * 3 + i];
+                cv[i] = a.cov[rc * 3 + i];
+            }
+            f32x16 a3[3];
+            chain_gemm<NP, 16, 3, false, true>(R, bh, a3, lane);
+            reload_b<NP>(a.delta_t + (int64_t)5 * Mp * 256 + blk * (256 * 32) + lo, hh, bh);
+            chain_gemm<NP, 16, 3, false, false>(R, bh, a3, lane);
+            float dm[3];
+            ipe_backward_tiles(a3, mu, cv, hh, dm);
+            if (live && hh == 0) {
+                a.d_mean[row * 3] = dm[0];
+                a.d_mean[row * 3 + 1] = dm[1];
+                a.d_mean[row * 3 + 2] = dm[2];
             }
         }
     }
@@ -605,12 +1018,51 @@ static PackTable fwd_table(int nc) {
 }
 
 template <int NP>
+static PackTable bwd_table(int nc) {
+    const PnLayout P = pn_layout(nc);
+    PackTable T;
+    T.n = B_COUNT;
+    const int ldv = PN_WIDTH + PN_VIEW_DIM, ld5 = PN_WIDTH + PN_ENC_DIM;
+    for (int i = 0; i < B_COUNT; ++i) {
+        PackLayer& L = T.L[i];
+        const int KS = bwd_ks(i), NT = bwd_nt(i);
+        fill_layer(L, bwd_chunk0<NP>(i), KS, NT, cks_of<NP>(KS, NT), 32 * NT);
+        if (i == B_COLOR) {  // A[i = hv feature][k = rgb channel] = Wc[k][i]
+            add_seg(L, P.wc, PN_WIDTH_COND, 0, 3, 1, 0);
+        } else if (i == B_VIEW) {  // A[i = bottleneck feature][k = hv feature] = Wv[k][i]
+            add_seg(L, P.wv, ldv, 0, PN_WIDTH_COND, 1, 0);
+        } else if (i == B_EXTRA) {  // k < 256: We[k][i] ; 256 <= k < 256 + nc: Wd[k - 256][i]
+            add_seg(L, P.we, PN_WIDTH, 0, PN_WIDTH, 1, 0);
+            add_seg(L, P.wd, PN_WIDTH, PN_WIDTH, nc, 1, 0);
+        } else if (i >= B_L7 && i <= B_L1) {  // A[i = input feature][k = output feature] = W_l[k][i]
+            const int l = 7 - (i - B_L7);
+            add_seg(L, P.w[l], l == 5 ? ld5 : PN_WIDTH, 0, PN_WIDTH, 1, 0);
+        } else {  // B_DENC: k < 256: W0[k][i] ; k >= 256: W5[k - 256][256 + i]
+            L.rows_valid = PN_ENC_DIM;
+            add_seg(L, P.w[0], PN_ENC_DIM, 0, PN_WIDTH, 1, 0);
+            add_seg(L, P.w[5], ld5, PN_WIDTH, PN_WIDTH, 1, PN_WIDTH);
+        }
+    }
+    T.nchunks = bwd_chunk0<NP>(B_COUNT);
+    return T;
+}
+
+template <int NP>
 static int pack_chain(const PackTable& T, const float* params, unsigned char* out, hipStream_t s) {
     const int64_t threads = (int64_t)T.nchunks * (Cfg<NP>::CF + 1) * 64;
     hipLaunchKernelGGL(k_chain_pack<NP>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, T, params, out);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
+template <int NP>
+static int pack_both(int nc, const float* params, unsigned char* out, hipStream_t s) {
+    int rc = pack_chain<NP>(fwd_table<NP>(nc), params, out, s);
+    if (rc != PN_OK) return rc;
+    return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, s);
+}
+
+template <typename K, typename A>
+static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s);
 
 static int g_chain_cus = 0;
 static int chain_grid(int64_t nst) {
@@ -622,6 +1074,25 @@ static int chain_grid(int64_t nst) {
     }
     return (int)(nst < g_chain_cus ? nst : g_chain_cus);
 }
+
+template <typename K, typename A>
+static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s) {
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return PN_ERR_HIP;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(chain_grid(nst)), dim3(CH_THREADS), lds_bytes, s, a);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+#define LAUNCH_CHAIN(KERNEL, planes, nst, args, s)                                                      \
+    do {                                                                                                \
+        static bool done3 = false, done1 = false;                                                       \
+        if ((planes) == 3) return launch_chain(KERNEL<3>, Cfg<3>::LDS_BYTES, done3, nst, args, s);      \
+        if ((planes) == 1) return launch_chain(KERNEL<1>, Cfg<1>::LDS_BYTES, done1, nst, args, s);      \
+        return PN_ERR_UNSUPPORTED;                                                                      \
+    } while (0)
 
 extern "C" {
 
@@ -637,8 +1108,8 @@ int pn_chain_pack(const float* params, int nc, int planes, void* pack, void* str
     if (!params || !pack) return PN_ERR_NULL;
     hipStream_t s = (hipStream_t)stream;
     unsigned char* out = (unsigned char*)pack;
-    if (planes == 3) return pack_chain<3>(fwd_table<3>(nc), params, out, s);
-    if (planes == 1) return pack_chain<1>(fwd_table<1>(nc), params, out, s);
+    if (planes == 3) return pack_both<3>(nc, params, out, s);
+    if (planes == 1) return pack_both<1>(nc, params, out, s);
     return PN_ERR_UNSUPPORTED;
 }
 
@@ -659,27 +1130,80 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     a.pack = (const unsigned char*)pack;
     a.mean = mean; a.cov = cov; a.viewdirs = viewdirs;
     a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
-    hipStream_t s = (hipStream_t)stream;
-    const int grid = chain_grid(a.nst);
-    if (planes == 3) {
-        static bool attr3 = false;
-        if (!attr3) {
-            if (hipFuncSetAttribute((const void*)k_chain_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<3>::LDS_BYTES) != hipSuccess) return PN_ERR_HIP;
-            attr3 = true;
-        }
-        hipLaunchKernelGGL(k_chain_fwd<3>, dim3(grid), dim3(CH_THREADS), Cfg<3>::LDS_BYTES, s, a);
-    } else if (planes == 1) {
-        static bool attr1 = false;
-        if (!attr1) {
-            if (hipFuncSetAttribute((const void*)k_chain_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<1>::LDS_BYTES) != hipSuccess) return PN_ERR_HIP;
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(k_chain_fwd<1>, dim3(grid), dim3(CH_THREADS), Cfg<1>::LDS_BYTES, s, a);
-    } else {
-        return PN_ERR_UNSUPPORTED;
-    }
-    PN_CHECK_LAUNCH();
-    return PN_OK;
+    LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, a, (hipStream_t)stream);
+}
+
+/* d sigma / d mean by one reverse sweep (see k_chain_dgrad).  rs_t: T32 [8][Mp*256] (r_0..r_7, kept for the second-order
+ * weight gradients); grad_mean [M,3] = + d sigma / d mean. */
+int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, const float* params, const void* pack,
+                          const float* mean, const float* cov, const uint32_t* masks, const float* raw_den, float* rs_t,
+                          float* grad_mean, void* stream) {
+    if (M <= 0) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    if (!params || !pack || !mean || !cov || !masks || !raw_den || !rs_t || !grad_mean) return PN_ERR_NULL;
+    SweepArgs a{};
+    a.M = M;
+    a.nst = pn_pad(M) / 128;
+    a.nc = nc;
+    a.density_bias = density_bias;
+    const int64_t slot = planes == 3 ? Cfg<3>::SLOT : Cfg<1>::SLOT;
+    const int f_all = planes == 3 ? fwd_chunk0<3>(F_COUNT) : fwd_chunk0<1>(F_COUNT);
+    const int b7 = planes == 3 ? bwd_chunk0<3>(B_L7) : bwd_chunk0<1>(B_L7);
+    const int ball = planes == 3 ? bwd_chunk0<3>(B_COUNT) : bwd_chunk0<1>(B_COUNT);
+    a.pack = (const unsigned char*)pack + (int64_t)(f_all + b7) * slot;
+    a.nchunk = ball - b7;
+    a.masks = masks; a.raw_den = raw_den; a.mean = mean; a.cov = cov;
+    a.wd0 = params + pn_layout(nc).wd;
+    a.vec_t = rs_t; a.out3 = grad_mean;
+    LAUNCH_CHAIN(k_chain_dgrad, planes, a.nst, a, (hipStream_t)stream);
+}
+
+/* forward-mode tangent sweep along v (see k_chain_tangent): edot_t T32 [Mp*96], tang_t T32 [8][Mp*256], sdot [M]. */
+int pn_chain_tangent(int64_t M, int nc, int planes, const float* params, const void* pack, const float* mean,
+                     const float* cov, const uint32_t* masks, const float* v, float* edot_t, float* tang_t, float* sdot,
+                     void* stream) {
+    if (M <= 0) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    if (!params || !pack || !mean || !cov || !masks || !v || !edot_t || !tang_t || !sdot) return PN_ERR_NULL;
+    SweepArgs a{};
+    a.M = M;
+    a.nst = pn_pad(M) / 128;
+    a.nc = nc;
+    a.pack = (const unsigned char*)pack;
+    a.nchunk = planes == 3 ? fwd_chunk0<3>(F_DEN) : fwd_chunk0<1>(F_DEN);
+    a.masks = masks; a.mean = mean; a.cov = cov; a.v = v;
+    a.wd0 = params + pn_layout(nc).wd;
+    a.vec_t = tang_t; a.edot_t = edot_t; a.sdot = sdot;
+    LAUNCH_CHAIN(k_chain_tangent, planes, a.nst, a, (hipStream_t)stream);
+}
+
+/* backward chain (see k_chain_bwd).  sdot / coef_t: second-order path (both or neither); d_mean nullable. */
+int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const void* pack, const uint32_t* masks,
+                      const float* raw_den, const float* d_raw_rgb, const float* d_raw_den, const float* sdot,
+                      const float* mean, const float* cov, float* drgb_t, float* dhv_t, float* d8_t, float* delta_t,
+                      float* coef_t, float* d_mean, void* stream) {
+    if (M <= 0) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    if (!pack || !masks || !raw_den || !d_raw_rgb || !d_raw_den || !drgb_t || !dhv_t || !d8_t || !delta_t) return PN_ERR_NULL;
+    if (d_mean && (!mean || !cov)) return PN_ERR_NULL;
+    if ((sdot == nullptr) != (coef_t == nullptr)) return PN_ERR_NULL;
+    BwdArgs a{};
+    a.M = M;
+    a.nst = pn_pad(M) / 128;
+    a.nc = nc;
+    a.density_bias = density_bias;
+    const int64_t slot = planes == 3 ? Cfg<3>::SLOT : Cfg<1>::SLOT;
+    const int f_all = planes == 3 ? fwd_chunk0<3>(F_COUNT) : fwd_chunk0<1>(F_COUNT);
+    a.pack = (const unsigned char*)pack + (int64_t)f_all * slot;
+    a.nchunk = d_mean ? (planes == 3 ? bwd_chunk0<3>(B_COUNT) : bwd_chunk0<1>(B_COUNT))
+                      : (planes == 3 ? bwd_chunk0<3>(B_DENC) : bwd_chunk0<1>(B_DENC));
+    a.masks = masks; a.raw_den = raw_den; a.d_rgb = d_raw_rgb; a.d_den = d_raw_den; a.sdot = sdot;
+    a.mean = mean; a.cov = cov;
+    a.drgb_t = drgb_t; a.dhv_t = dhv_t; a.d8_t = d8_t; a.delta_t = delta_t; a.coef_t = coef_t; a.d_mean = d_mean;
+    LAUNCH_CHAIN(k_chain_bwd, planes, a.nst, a, (hipStream_t)stream);
 }
 
 }  // extern "C"
