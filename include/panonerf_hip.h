@@ -169,6 +169,55 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_dens
                     const float* const* drsweep_host, float* const* dwork_host, const int* dtangent_host,
                     void* stream, void* side_stream);
 
+
+/* ---- fused on-chip MLP chains (pn_chain.hip) ---------------------------------------------------------------------
+ * The same MLP (models/pano_mip_nerf.py:95-114, models/mip_nerf.py:81-102), encodings (models/mip.py:394-441) and
+ * their reverse / forward-mode passes as ONE kernel per pass: every layer is computed transposed on
+ * v_mfma_f32_32x32x16_bf16, a wave carries the activations of its 32 samples from layer to layer in registers, the
+ * weights stream through an LDS ring by LDS-DMA.  planes = 3: exact 3-term bf16 split (fp32 accuracy); planes = 1:
+ * plain bf16 operands, fp32 accumulate.  Sample-row tensors these kernels exchange are in the "T32" layout:
+ * float[Mp/32][F][32] (sample-minor, Mp = pn_pad_rows(M)); gate words are uint32 [9][Mp][8]. */
+int64_t pn_chain_pack_bytes(int planes);
+int pn_chain_pack(const float* params, int num_density_channels, int planes, void* pack, void* stream);
+/* floats of acts_t: h0..h7 [256] x 8, bottleneck | view encoding [288], view hidden [128] */
+int64_t pn_chain_acts_floats(int64_t M);
+int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, int planes,
+                     const void* pack, const float* mean, const float* cov, const float* viewdirs, float* enc_t,
+                     float* acts_t, uint32_t* masks, float* raw_rgb /*[M,3]*/, float* raw_density /*[M,nc]*/,
+                     void* stream);
+/* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep; rs_t: T32 [8][Mp*256] */
+int pn_chain_density_grad(int64_t M, int num_density_channels, int planes, float density_bias, const float* params,
+                          const void* pack, const float* mean, const float* cov, const uint32_t* masks,
+                          const float* raw_density, float* rs_t, float* grad_mean /*[M,3]*/, void* stream);
+/* forward-mode tangent sweep along v_gradmean (the double backward of the normals block) */
+int pn_chain_tangent(int64_t M, int num_density_channels, int planes, const float* params, const void* pack,
+                     const float* mean, const float* cov, const uint32_t* masks, const float* v_gradmean,
+                     float* edot_t /*T32 [Mp*96]*/, float* tang_t /*T32 [8][Mp*256]*/, float* sdot /*[M]*/, void* stream);
+/* data-gradient chain.  drgb_t T32 [Mp*32], d8_t T32 [Mp*288], coef_t T32 [Mp*32] must be zero-filled by the caller
+ * once (the kernel rewrites the rows it owns); sdot / coef_t: second-order path (both or neither); d_mean nullable. */
+int pn_chain_backward(int64_t M, int num_density_channels, int planes, float density_bias, const void* pack,
+                      const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
+                      const float* d_raw_density, const float* sdot, const float* mean, const float* cov,
+                      float* drgb_t, float* dhv_t /*T32 [Mp*128]*/, float* d8_t, float* delta_t /*T32 [8][Mp*256]*/,
+                      float* coef_t, float* d_mean /*[M,3]*/, void* stream);
+/* one evaluation's tensors for the weight gradients (host struct of device pointers) */
+typedef struct PnChainEval {
+    int64_t M;
+    const float* enc_t;
+    const float* acts_t;
+    const float* drgb_t;
+    const float* dhv_t;
+    const float* d8_t;
+    const float* delta_t;
+    const float* rs_t;   /* second-order rows: all four or none */
+    const float* edot_t;
+    const float* tang_t;
+    const float* coef_t;
+} PnChainEval;
+int64_t pn_chain_wgrad_work_floats(void);
+int pn_chain_wgrad(int n_evals, const PnChainEval* evals_host, int num_density_channels, int planes, float* grads,
+                   float* work, int64_t work_floats, void* stream);
+
 /* ---- volumetric rendering ---------------------------------------------------------
  * compute_graph activations (models/pano_mip_nerf.py:273-278) + volumetric_rendering
  * (models/mip.py:444-483).  R rays of N samples; dirs [R or dir_mod, 3] (ray r uses

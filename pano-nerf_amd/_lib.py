@@ -54,6 +54,8 @@ SIGNATURES = {
     "pn_chain_density_grad": ("i", "liif" + "p" * 8 + "p"),
     "pn_chain_tangent": ("i", "lii" + "p" * 9 + "p"),
     "pn_chain_backward": ("i", "liif" + "p" * 14 + "p"),
+    "pn_chain_wgrad_work_floats": ("l", ""),
+    "pn_chain_wgrad": ("i", "ipiipplp"),
     "pn_mfma_probe": ("i", "piip"),
     "pn_prof_enable": ("i", "i"),
     "pn_prof_read": ("i", "ippp"),

@@ -974,6 +974,174 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_bwd(BwdArgs a) {
     R.drain();
 }
 
+
+// ------------------------------------------------------------------------------------- weight gradients (TN GEMM)
+// dW[N1 x N2] (+)= sum over samples X[s][i] * Y[s][j] with X, Y in the T32 layout (sample-minor), on the bf16 matrix
+// cores: A = X^T (k = sample), B = Y.  A workgroup owns the whole [TMW x TNW] result for a contiguous range of
+// 16-sample half blocks (split over samples; per-workgroup slabs are reduced afterwards).  Staging: fp32 from HBM to
+// registers (full 64-B half rows, coalesced), split ONCE per element into NP bf16 planes, 8-B LDS writes into
+// [plane][feature][16 samples] images (the two 16-B pieces of a row swapped on features with bit 3 set: conflict-free
+// for the writes and for the ds_read_b128 fragment reads); two LDS buffers, one barrier per half block.  Row sums of X
+// (bias gradients) are accumulated from the fp32 values on the way in.
+struct WSeg {
+    const float* X;  // feature 0 of the X sub-range in block 0
+    const float* Y;
+    int64_t nhalf;   // 16-sample half blocks
+    int FX, FY;      // features per block of the tensors X / Y live in
+    int bias;        // rows of this segment count towards the row sums of X (the second-order rows do not)
+};
+struct WgArgs {
+    WSeg seg[4];
+    int nseg;
+    int64_t half_total, per;
+    float* slab;
+    int64_t slab_stride;
+    int bias;
+};
+
+template <int NP, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
+    constexpr int NTH = 64 * WM * WN, TMW = 32 * TM * WM, TNW = 32 * TN * WN;
+    constexpr int PX = TMW * 16, PY = TNW * 16;     // bf16 elements per plane
+    constexpr int BUF = NP * (PX + PY);             // per buffer
+    constexpr int CX = TMW * 4, CY = TNW * 4;       // 16-B pieces per half block
+    constexpr int LX = (CX + NTH - 1) / NTH, LY = (CY + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int64_t h0 = (int64_t)blockIdx.x * a.per;
+    int64_t h1 = h0 + a.per;
+    if (h1 > a.half_total) h1 = a.half_total;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum[LX];
+#pragma unroll
+    for (int i = 0; i < LX; ++i) bsum[i] = 0.f;
+
+    f32x4 xr[LX], yr[LY];
+    float bw = 0.f;  // bias weight of the half block held in xr
+    auto load = [&](int64_t h) {
+        int sg = 0;
+        int64_t hb = h;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (sg == i && i + 1 < a.nseg && hb >= a.seg[i].nhalf) {
+                hb -= a.seg[i].nhalf;
+                sg = i + 1;
+            }
+        const WSeg& S = a.seg[sg];
+        bw = S.bias ? 1.f : 0.f;
+        const int64_t blk = hb >> 1;
+        const int half = (int)(hb & 1);
+        const float* xb = S.X + blk * ((int64_t)S.FX * 32) + half * 16;
+        const float* yb = S.Y + blk * ((int64_t)S.FY * 32) + half * 16;
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int idx = tid + NTH * i;
+            if (CX % NTH == 0 || idx < CX) xr[i] = *reinterpret_cast<const f32x4*>(xb + (idx >> 2) * 32 + (idx & 3) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < LY; ++i) {
+            const int idx = tid + NTH * i;
+            if (CY % NTH == 0 || idx < CY) yr[i] = *reinterpret_cast<const f32x4*>(yb + (idx >> 2) * 32 + (idx & 3) * 4);
+        }
+    };
+    auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v) {
+        const int f = idx >> 2, q = idx & 3;
+        const int o = f * 16 + (((q >> 1) ^ ((f >> 3) & 1)) << 3) + (q & 1) * 4;
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 hv, mv, lv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const __bf16 hb = (__bf16)v[c];
+            hv[c] = hb;
+            if constexpr (NP == 3) {
+                const float r1 = v[c] - (float)hb;
+                const __bf16 mb = (__bf16)r1;
+                mv[c] = mb;
+                lv[c] = (__bf16)(r1 - (float)mb);
+            }
+        }
+        *reinterpret_cast<bf16x4*>(plane0 + o) = hv;
+        if constexpr (NP == 3) {
+            *reinterpret_cast<bf16x4*>(plane0 + pstride + o) = mv;
+            *reinterpret_cast<bf16x4*>(plane0 + 2 * pstride + o) = lv;
+        }
+    };
+    auto stage = [&](int buf) {
+        unsigned short* xs = smem + buf * BUF;
+        unsigned short* ys = xs + NP * PX;
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int idx = tid + NTH * i;
+            if (CX % NTH == 0 || idx < CX) {
+                put(xs, PX, idx, xr[i]);
+                bsum[i] += bw * ((xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LY; ++i) {
+            const int idx = tid + NTH * i;
+            if (CY % NTH == 0 || idx < CY) put(ys, PY, idx, yr[i]);
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    auto frag = [&](const unsigned short* plane, int feature) {
+        return *reinterpret_cast<const bf16x8*>(plane + feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3));
+    };
+    if (h0 < h1) {
+        load(h0);
+        for (int64_t h = h0; h < h1; ++h) {
+            const int buf = (int)((h - h0) & 1);
+            stage(buf);
+            __syncthreads();
+            if (h + 1 < h1) load(h + 1);
+            const unsigned short* xs = smem + buf * BUF;
+            const unsigned short* ys = xs + NP * PX;
+            BFrag<NP> af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) af[i].p[p] = frag(xs + p * PX, 32 * (wm * TM + i) + fr);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                BFrag<NP> bf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bf.p[p] = frag(ys + p * PY, 32 * (wn * TN + j) + fr);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split<NP>(af[i], bf, acc[i][j]);
+            }
+        }
+    }
+    float* out = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * (wm * TM + i) + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                out[(int64_t)row * TNW + 32 * (wn * TN + j) + fr] = acc[i][j][e];
+            }
+    if (a.bias) {
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            const int idx = tid + NTH * i;
+            if ((idx & 3) == 0 && (CX % NTH == 0 || idx < CX)) out[(int64_t)TMW * TNW + (idx >> 2)] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- host side
 static void fill_layer(PackLayer& L, int chunk0, int KS, int NT, int CKS, int rows_valid) {
     L.chunk0 = chunk0; L.KS = KS; L.NT = NT; L.CKS = CKS; L.rows_valid = rows_valid;
@@ -1094,6 +1262,57 @@ static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, c
         return PN_ERR_UNSUPPORTED;                                                                      \
     } while (0)
 
+
+// ---- weight gradients of one training step -------------------------------------------------------------------
+struct WgJob {
+    WSeg seg[4];
+    int nseg;
+    int cfg;            // 0: 256x256, 1: 256x96, 2: 128x288, 3: 32x256, 4: 32x128
+    int rows, cols;     // valid part of the result
+    float* dst; int ldd;
+    float* dbias;       // or null
+};
+static const int kCfgM[5] = {256, 256, 128, 32, 32};
+static const int kCfgN[5] = {256, 96, 288, 256, 128};
+
+template <int NP>
+static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipStream_t s) {
+    WgArgs a{};
+    int64_t total = 0;
+    for (int i = 0; i < j.nseg; ++i) {
+        a.seg[i] = j.seg[i];
+        total += j.seg[i].nhalf;
+    }
+    a.nseg = j.nseg;
+    a.half_total = total;
+    const int TMW = kCfgM[j.cfg], TNW = kCfgN[j.cfg];
+    const int64_t stride = (int64_t)TMW * TNW + TMW;
+    int cus = chain_grid(1 << 30);
+    int64_t nsplit = cus;
+    if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;  // at least four half blocks per workgroup
+    if (nsplit < 1) nsplit = 1;
+    a.per = (total + nsplit - 1) / nsplit;
+    nsplit = (total + a.per - 1) / a.per;
+    if (nsplit * stride + 64 * stride > work_floats) return PN_ERR_BAD_SHAPE;
+    a.slab = work;
+    a.slab_stride = stride;
+    a.bias = j.dbias != nullptr;
+    const dim3 grid((unsigned)nsplit);
+    switch (j.cfg) {
+        case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 8, 1>), grid, dim3(512), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 9, 4, 1>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 2, 1, 4>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 1, 1, 4>), grid, dim3(256), 0, s, a); break;
+    }
+    PN_CHECK_LAUNCH();
+    float* scratch = work + nsplit * stride;
+    int rc = pn_launch_reduce_rows(work, nsplit, stride, j.rows, j.cols, TNW, j.dst, j.ldd, 1, scratch, s);
+    if (rc != PN_OK) return rc;
+    if (j.dbias) rc = pn_launch_reduce_rows(work + (int64_t)TMW * TNW, nsplit, stride, 1, j.rows, TMW, j.dbias, j.rows, 1, scratch, s);
+    return rc;
+}
+
 extern "C" {
 
 // bytes of the packed chains for `planes` (3: exact split, 1: plain bf16): [forward chain | backward chain]
@@ -1204,6 +1423,103 @@ int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const v
     a.mean = mean; a.cov = cov;
     a.drgb_t = drgb_t; a.dhv_t = dhv_t; a.d8_t = d8_t; a.delta_t = delta_t; a.coef_t = coef_t; a.d_mean = d_mean;
     LAUNCH_CHAIN(k_chain_bwd, planes, a.nst, a, (hipStream_t)stream);
+}
+
+
+int64_t pn_chain_wgrad_work_floats(void) {
+    const int64_t stride = 256 * 288 + 256;
+    return (256 + 64) * stride + 1024;
+}
+
+/* Weight and bias gradients of ONE training step from the T32 tensors the chain kernels left behind: one split-bf16
+ * (or plain bf16) TN GEMM per layer over the sample blocks of all `n` evaluations (and, for an evaluation with
+ * rs_t / tang_t, its second-order rows r_l^T hdot_{l-1}); accumulates (+=) into the flat gradient block. */
+int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grads, float* work, int64_t work_floats,
+                   void* stream) {
+    if (n < 1 || n > 3) return PN_ERR_BAD_SHAPE;
+    if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
+    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    if (!ev || !grads || !work) return PN_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const PnLayout L = pn_layout(nc);
+    int n2 = 0;
+    for (int e = 0; e < n; ++e) {
+        if (ev[e].M <= 0 || !ev[e].enc_t || !ev[e].acts_t || !ev[e].drgb_t || !ev[e].dhv_t || !ev[e].d8_t || !ev[e].delta_t)
+            return PN_ERR_NULL;
+        if (ev[e].rs_t) {
+            if (!ev[e].edot_t || !ev[e].tang_t || !ev[e].coef_t) return PN_ERR_NULL;
+            ++n2;
+        }
+    }
+    if (n + n2 > 4) return PN_ERR_UNSUPPORTED;
+    auto run = [&](const WgJob& j) { return planes == 3 ? run_wgrad_job<3>(j, work, work_floats, s) : run_wgrad_job<1>(j, work, work_floats, s); };
+    auto mp = [&](int e) { return pn_pad(ev[e].M); };
+    auto act = [&](int e, int slot) { return ev[e].acts_t + act_off(slot, mp(e)); };
+    int rc;
+    // trunk layers (layer 5: hidden columns here, skip columns below)
+    for (int l = 0; l < 8; ++l) {
+        WgJob j{};
+        for (int e = 0; e < n; ++e) {
+            const int64_t Mp = mp(e);
+            j.seg[j.nseg++] = WSeg{ev[e].delta_t + (int64_t)l * Mp * 256, l == 0 ? ev[e].enc_t : act(e, l - 1), Mp / 16, 256,
+                                   l == 0 ? 96 : 256, 1};
+            if (ev[e].rs_t)
+                j.seg[j.nseg++] = WSeg{ev[e].rs_t + (int64_t)l * Mp * 256,
+                                       l == 0 ? ev[e].edot_t : ev[e].tang_t + (int64_t)(l - 1) * Mp * 256, Mp / 16, 256,
+                                       l == 0 ? 96 : 256, 0};
+        }
+        j.cfg = l == 0 ? 1 : 0;
+        j.rows = 256;
+        j.cols = l == 0 ? 96 : 256;
+        j.dst = grads + L.w[l];
+        j.ldd = l == 0 ? 96 : (l == 5 ? 352 : 256);
+        j.dbias = grads + L.b[l];
+        if ((rc = run(j)) != PN_OK) return rc;
+        if (l == 5) {
+            WgJob k{};
+            for (int e = 0; e < n; ++e) {
+                const int64_t Mp = mp(e);
+                k.seg[k.nseg++] = WSeg{ev[e].delta_t + (int64_t)5 * Mp * 256, ev[e].enc_t, Mp / 16, 256, 96, 0};
+                if (ev[e].rs_t) k.seg[k.nseg++] = WSeg{ev[e].rs_t + (int64_t)5 * Mp * 256, ev[e].edot_t, Mp / 16, 256, 96, 0};
+            }
+            k.cfg = 1; k.rows = 256; k.cols = 96;
+            k.dst = grads + L.w[5] + 256; k.ldd = 352; k.dbias = nullptr;
+            if ((rc = run(k)) != PN_OK) return rc;
+        }
+    }
+    {  // extra layer: d bottleneck^T h7
+        WgJob j{};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t, act(e, 7), mp(e) / 16, 288, 256, 1};
+        j.cfg = 0; j.rows = 256; j.cols = 256; j.dst = grads + L.we; j.ldd = 256; j.dbias = grads + L.be;
+        if ((rc = run(j)) != PN_OK) return rc;
+    }
+    {  // density head: d raw_density^T h7 (+ softplus' rows against hdot_7 into row 0)
+        WgJob j{};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t + 256 * 32, act(e, 7), mp(e) / 16, 288, 256, 1};
+        j.cfg = 3; j.rows = nc; j.cols = 256; j.dst = grads + L.wd; j.ldd = 256; j.dbias = grads + L.bd;
+        if ((rc = run(j)) != PN_OK) return rc;
+        WgJob k{};
+        for (int e = 0; e < n; ++e)
+            if (ev[e].rs_t) k.seg[k.nseg++] = WSeg{ev[e].coef_t, ev[e].tang_t + (int64_t)7 * mp(e) * 256, mp(e) / 16, 32, 256, 0};
+        if (k.nseg) {
+            k.cfg = 3; k.rows = 1; k.cols = 256; k.dst = grads + L.wd; k.ldd = 256; k.dbias = nullptr;
+            if ((rc = run(k)) != PN_OK) return rc;
+        }
+    }
+    {  // view layer: d hv^T [bottleneck | view encoding]
+        WgJob j{};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].dhv_t, act(e, 8), mp(e) / 16, 128, 288, 1};
+        j.cfg = 2; j.rows = 128; j.cols = PN_WIDTH + PN_VIEW_DIM; j.dst = grads + L.wv; j.ldd = PN_WIDTH + PN_VIEW_DIM;
+        j.dbias = grads + L.bv;
+        if ((rc = run(j)) != PN_OK) return rc;
+    }
+    {  // colour head: d rgb^T hv
+        WgJob j{};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].drgb_t, act(e, 9), mp(e) / 16, 32, 128, 1};
+        j.cfg = 4; j.rows = 3; j.cols = 128; j.dst = grads + L.wc; j.ldd = 128; j.dbias = grads + L.bc;
+        if ((rc = run(j)) != PN_OK) return rc;
+    }
+    return PN_OK;
 }
 
 }  // extern "C"

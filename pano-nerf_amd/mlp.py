@@ -59,6 +59,7 @@ class RadianceMLP(torch.nn.Module):
         self.flat = None
         self._version_packed = None
         self._wpack = None
+        self._chain = {}  # planes -> (version, packed chains of the fused kernels)
         self.last_flat_grad = None
         self._flatten()
 
@@ -81,6 +82,7 @@ class RadianceMLP(torch.nn.Module):
         self.flat = flat
         self._wpack = None
         self._version_packed = None
+        self._chain = {}
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
@@ -110,6 +112,24 @@ class RadianceMLP(torch.nn.Module):
             self._version_packed = version
         return self._wpack
 
+    def _version(self):
+        flat = self.flat_params()
+        return tuple(p._version for _, p in self.named_in_order()) + (flat._version, flat.data_ptr())
+
+    def chain_packed(self, stream, planes):
+        """Fragment-ordered bf16 planes of every weight matrix, in both directions, for the fused chain kernels
+        (pn_chain_pack); rebuilt when any parameter changed, like `packed`."""
+        flat = self.flat_params()
+        version = self._version()
+        hit = self._chain.get(planes)
+        if hit is None or hit[0] != version or hit[1].device != flat.device:
+            buf = hit[1] if (hit is not None and hit[1].device == flat.device) else torch.empty(
+                int(_lib.load().pn_chain_pack_bytes(planes)), dtype=torch.uint8, device=flat.device)
+            _lib.call("pn_chain_pack", flat.data_ptr(), self.num_density_channels, planes, buf.data_ptr(), stream)
+            self._chain[planes] = (version, buf)
+            hit = self._chain[planes]
+        return hit[1]
+
     def grad_views(self, flat_grad):
         return [flat_grad[self._offsets[k]:self._offsets[k] + p.numel()].view(p.shape) for k, p in self.named_in_order()]
 
@@ -120,3 +140,4 @@ class RadianceMLP(torch.nn.Module):
 def mark_dirty(mlp):
     """Tell the container its flat block was written outside torch (e.g. by pn_adam_step)."""
     mlp._version_packed = None
+    mlp._chain = {}

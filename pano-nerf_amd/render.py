@@ -8,6 +8,8 @@ density-gradient normals.
 
 There is no CPU / eager fallback: tensors must live on a HIP device and the library must be built.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -22,24 +24,37 @@ def _f32(x):
 
 
 class _Eval:
-    """Buffers of one MLP evaluation over M sample rows (all caller-owned HBM)."""
+    """Buffers of one MLP evaluation over M sample rows (all caller-owned HBM).  planes = 0: layer-wise GEMM path
+    (row-major activations); planes = 3 / 1: fused chain kernels (T32 sample-minor tensors, see pn_chain.hip)."""
 
-    def __init__(self, M, rows_per_ray, viewdirs, nc, dev):
+    def __init__(self, M, rows_per_ray, viewdirs, nc, dev, planes=0):
         self.M, self.rows_per_ray, self.nc = M, rows_per_ray, nc
         self.view_rows = viewdirs.shape[0]
         self.viewdirs = viewdirs
+        self.planes = planes
         Mp = int(_lib.load().pn_pad_rows(M))
         self.Mp = Mp
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.mean, self.cov = e(M, 3), e(M, 3)
-        self.enc = e(Mp, 96)
-        self.viewenc, self.viewbias = e(self.view_rows, 27), e(self.view_rows, 128)
-        self.acts = e(10, Mp, 256)
+        if planes:
+            self.enc = e(Mp * 96)                                          # T32 [96]
+            self.acts = e(int(_lib.load().pn_chain_acts_floats(M)))        # T32 h0..h7, bottleneck | viewenc, view hidden
+        else:
+            self.enc = e(Mp, 96)
+            self.viewenc, self.viewbias = e(self.view_rows, 27), e(self.view_rows, 128)
+            self.acts = e(10, Mp, 256)
         self.masks = torch.empty(9, Mp, 8, dtype=torch.int32, device=dev)  # ReLU gates as bit masks
         self.raw_rgb, self.raw_den = e(M, 3), e(M, nc)
         self.t = None
         self.rsweep = None
         self.gmean = None
+
+
+def _planes_of(mode):
+    try:
+        return {"fused": 3, "fused_bf16": 1, "layerwise": 0}[mode]
+    except KeyError:
+        raise ValueError(f"mlp_mode must be 'fused', 'fused_bf16' or 'layerwise', got {mode!r}")
 
 
 class _Cfg:
@@ -50,6 +65,11 @@ class _Cfg:
 
 
 def _mlp_forward(ev, params, wpack, st):
+    if ev.planes:
+        _lib.call("pn_chain_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, ev.planes, wpack.data_ptr(),
+                  ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), ev.acts.data_ptr(),
+                  ev.masks.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), st)
+        return
     _lib.call("pn_mlp_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, params.data_ptr(), wpack.data_ptr(),
               ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
               ev.viewbias.data_ptr(), ev.acts.data_ptr(), ev.masks.data_ptr(), ev.raw_rgb.data_ptr(),
@@ -112,6 +132,53 @@ def _mlp_backward(ev, cfg, params, wpack, d_raw_rgb, d_raw_den, v, d_mean, flat_
     return work
 
 
+class _ChainEvalC(ctypes.Structure):
+    """PnChainEval of include/panonerf_hip.h"""
+    _fields_ = [("M", ctypes.c_int64), ("enc_t", ctypes.c_void_p), ("acts_t", ctypes.c_void_p),
+                ("drgb_t", ctypes.c_void_p), ("dhv_t", ctypes.c_void_p), ("d8_t", ctypes.c_void_p),
+                ("delta_t", ctypes.c_void_p), ("rs_t", ctypes.c_void_p), ("edot_t", ctypes.c_void_p),
+                ("tang_t", ctypes.c_void_p), ("coef_t", ctypes.c_void_p)]
+
+
+def _chain_backward(ev, cfg, params, pack, d_raw_rgb, d_raw_den, v, d_mean, st):
+    """Fused data-gradient chain of one evaluation (tangent sweep first when v = dL/d(grad_mean) is given); leaves the
+    T32 tensors the weight-gradient GEMMs read on `ev`."""
+    dev = d_raw_rgb.device
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    Mp = ev.Mp
+    sdot = None
+    ev.edot = ev.tang = ev.coef = None
+    if v is not None:
+        ev.edot, ev.tang, sdot = e(Mp * 96), e(8 * Mp * 256), e(ev.M)
+        _lib.call("pn_chain_tangent", ev.M, ev.nc, ev.planes, params.data_ptr(), pack.data_ptr(), ev.mean.data_ptr(),
+                  ev.cov.data_ptr(), ev.masks.data_ptr(), v.data_ptr(), ev.edot.data_ptr(), ev.tang.data_ptr(),
+                  sdot.data_ptr(), st)
+        ev.coef = z(Mp * 32)
+    ev.drgb, ev.dhv, ev.d8, ev.delta = z(Mp * 32), e(Mp * 128), z(Mp * 288), e(8 * Mp * 256)
+    _lib.call("pn_chain_backward", ev.M, ev.nc, ev.planes, cfg.density_bias, pack.data_ptr(), ev.masks.data_ptr(),
+              ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(), _lib.ptr(sdot), ev.mean.data_ptr(),
+              ev.cov.data_ptr(), ev.drgb.data_ptr(), ev.dhv.data_ptr(), ev.d8.data_ptr(), ev.delta.data_ptr(),
+              _lib.ptr(ev.coef), _lib.ptr(d_mean), st)
+
+
+def _chain_wgrad(evals, nc, planes, flat_grad, st):
+    """One TN GEMM per layer over the sample blocks of every evaluation of the step."""
+    lib = _lib.load()
+    arr = (_ChainEvalC * len(evals))()
+    for i, ev in enumerate(evals):
+        second = ev.tang is not None
+        arr[i] = _ChainEvalC(ev.M, ev.enc.data_ptr(), ev.acts.data_ptr(), ev.drgb.data_ptr(), ev.dhv.data_ptr(),
+                             ev.d8.data_ptr(), ev.delta.data_ptr(), ev.rsweep.data_ptr() if second else None,
+                             ev.edot.data_ptr() if second else None, ev.tang.data_ptr() if second else None,
+                             ev.coef.data_ptr() if second else None)
+    n = int(lib.pn_chain_wgrad_work_floats())
+    work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
+    _lib.check(lib.pn_chain_wgrad(len(evals), ctypes.cast(arr, ctypes.c_void_p), nc, planes, flat_grad.data_ptr(),
+                                  work.data_ptr(), n, st), "pn_chain_wgrad")
+    return work
+
+
 class _RenderFn(torch.autograd.Function):
     """(rays, env rays, noise, 24 parameters) -> the ten differentiable outputs of both levels."""
 
@@ -126,13 +193,14 @@ class _RenderFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             params = mlp.flat_params()
-            wpack = mlp.packed(st)
+            planes = cfg.planes
+            wpack = mlp.chain_packed(st, planes) if planes else mlp.packed(st)
             B, N, nc = o.shape[0], cfg.num_samples, cfg.nc
             S, M = N + 1, o.shape[0] * cfg.num_samples
             e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             keep = cfg.keep  # inference (no_grad): release the big activation buffers as soon as possible
             # ---- level 0: stratified samples
-            e0 = _Eval(M, N, vd, nc, dev)
+            e0 = _Eval(M, N, vd, nc, dev, planes)
             e0.t = e(B, S)
             _lib.call("pn_sample_coarse", B, N, o.data_ptr(), d.data_ptr(), radii.data_ptr(), near.data_ptr(),
                       far.data_ptr(), _lib.ptr(t_rand), e0.t.data_ptr(), e0.mean.data_ptr(), e0.cov.data_ptr(), st)
@@ -141,7 +209,7 @@ class _RenderFn(torch.autograd.Function):
             if not keep:
                 e0.acts = e0.masks = e0.enc = None
             # ---- level 1: PDF resample (no gradient through the weights: stop_resample_grad)
-            e1 = _Eval(M, N, vd, nc, dev)
+            e1 = _Eval(M, N, vd, nc, dev, planes)
             e1.t = e(B, S)
             _lib.call("pn_resample", B, N, e0.t.data_ptr(), w0.data_ptr(), cfg.resample_padding, _lib.ptr(u_rand),
                       o.data_ptr(), d.data_ptr(), radii.data_ptr(), e1.t.data_ptr(), e1.mean.data_ptr(),
@@ -153,10 +221,16 @@ class _RenderFn(torch.autograd.Function):
             if cfg.normals:
                 e1.rsweep = e(8, e1.Mp, 256)
                 e1.gmean = e(M, 3)
-                scratch = e(e1.Mp, 96)
-                _lib.call("pn_density_grad", M, nc, cfg.density_bias, params.data_ptr(), wpack.data_ptr(),
-                          e1.mean.data_ptr(), e1.cov.data_ptr(), e1.acts.data_ptr(), e1.masks.data_ptr(),
-                          e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), scratch.data_ptr(), e1.gmean.data_ptr(), st)
+                scratch = None
+                if planes:
+                    _lib.call("pn_chain_density_grad", M, nc, planes, cfg.density_bias, params.data_ptr(),
+                              wpack.data_ptr(), e1.mean.data_ptr(), e1.cov.data_ptr(), e1.masks.data_ptr(),
+                              e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), e1.gmean.data_ptr(), st)
+                else:
+                    scratch = e(e1.Mp, 96)
+                    _lib.call("pn_density_grad", M, nc, cfg.density_bias, params.data_ptr(), wpack.data_ptr(),
+                              e1.mean.data_ptr(), e1.cov.data_ptr(), e1.acts.data_ptr(), e1.masks.data_ptr(),
+                              e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), scratch.data_ptr(), e1.gmean.data_ptr(), st)
                 normal = e(B, 3)
                 ort_ray = e(B) if cfg.use_ort else None
                 albedo = e(B, 3) if (cfg.surf and nc == 5) else None
@@ -171,7 +245,7 @@ class _RenderFn(torch.autograd.Function):
                 e1.acts = e1.masks = e1.enc = None
             if cfg.surf:
                 D, Ne = env_d.shape[0], cfg.num_env_samples
-                ee = _Eval(B * D * Ne, Ne, env_d, nc, dev)
+                ee = _Eval(B * D * Ne, Ne, env_d, nc, dev, planes)
                 ee.t = e(B * D, Ne + 1)
                 _lib.call("pn_sample_env", B, D, Ne, o.data_ptr(), d.data_ptr(), dist1.data_ptr(), env_d.data_ptr(),
                           env_rad.data_ptr(), env_near.data_ptr(), env_far.data_ptr(), _lib.ptr(env_rand),
@@ -240,8 +314,12 @@ class _RenderFn(torch.autograd.Function):
                 d_rr, d_rd = z(ee.M, 3), z(ee.M, nc)
                 _composite_backward(ee, B * D, Ne, cfg, False, env_d, D, d_env, None, None, d_rr, d_rd, st)
                 d_mean_e = z(ee.M, 3)
-                pending.append((ee, _mlp_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, flat_grad, st,
-                                                  defer=cfg.batch_wgrad), False))
+                if cfg.planes:
+                    _chain_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, st)
+                    pending.append(ee)
+                else:
+                    pending.append((ee, _mlp_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, flat_grad, st,
+                                                      defer=cfg.batch_wgrad), False))
                 _lib.call("pn_env_origin_backward", B, D * Ne, d_mean_e.data_ptr(), d.data_ptr(), d_dist1.data_ptr(), st)
             d_rr, d_rd = z(M, 3), z(M, nc)
             d_w1 = v = None
@@ -254,14 +332,23 @@ class _RenderFn(torch.autograd.Function):
                           e1.raw_den.data_ptr(), d.data_ptr(), d_normal.data_ptr(), _lib.ptr(d_ort_ray),
                           _lib.ptr(d_albedo), d_w1.data_ptr(), v.data_ptr(), d_rd.data_ptr(), st)
             _composite_backward(e1, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp1, B, 3), d_dist1, d_w1, d_rr, d_rd, st)
-            pending.append((e1, _mlp_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, flat_grad, st,
-                                              defer=cfg.batch_wgrad), v is not None))
-            if not cfg.batch_wgrad:
-                pending = []
+            if cfg.planes:
+                _chain_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, st)
+                pending.append(e1)
+            else:
+                pending.append((e1, _mlp_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, flat_grad, st,
+                                                  defer=cfg.batch_wgrad), v is not None))
+                if not cfg.batch_wgrad:
+                    pending = []
             d_rr0, d_rd0 = z(M, 3), z(M, nc)
             _composite_backward(e0, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp0, B, 3), gz(g_dist0, B), None, d_rr0,
                                 d_rd0, st)
-            _mlp_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, flat_grad, st, deferred=pending)
+            if cfg.planes:
+                _chain_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, st)
+                pending.append(e0)
+                _chain_wgrad(pending, nc, cfg.planes, flat_grad, st)
+            else:
+                _mlp_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, flat_grad, st, deferred=pending)
             pending = []
         mlp.last_flat_grad = flat_grad
         ctx.pack = None
@@ -323,6 +410,11 @@ class _RenderBase(torch.nn.Module):
         # time-shared run measured 2 % SLOWER (62.4 k vs 61.0 k rays/s at 4096 rays, 50.8 k vs 49.4 k at 512)
         self.overlap_weight_grads = False
         self.batch_weight_grads = True    # one weight-gradient GEMM per layer over env + level-1 + level-0 rows
+        # MLP arithmetic / kernel family: "fused" = on-chip chains, exact 3-term bf16 split (fp32 accuracy);
+        # "fused_bf16" = on-chip chains, plain bf16 operands (BASELINE configs[1]); "layerwise" = one exact-fp32 MFMA
+        # GEMM per layer (round-1 path).  PN_MLP_MODE overrides the default.
+        import os
+        self.mlp_mode = os.environ.get("PN_MLP_MODE", "fused")
 
     def _noise(self, randomized, B, dev, want_env):
         if not randomized:
@@ -352,7 +444,7 @@ class _RenderBase(torch.nn.Module):
         cfg = _Cfg(num_samples=self.num_samples, nc=self._NC, density_bias=self.density_bias,
                    rgb_padding=self.rgb_padding, resample_padding=self.resample_padding,
                    white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
-                   num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads,
+                   num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads, planes=_planes_of(self.mlp_mode),
                    batch_wgrad=self.batch_weight_grads,
                    keep=torch.is_grad_enabled() and any(p.requires_grad for p in self.mlp.parameters()))
         plist = [p for _, p in self.mlp.named_in_order()]

@@ -100,7 +100,45 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     want_dd[:, 0] += sg * (1 - sg) * sdot
     print("  d_den(+2nd)", rel(d8[:, 256:256 + nc], want_dd), float(d8[:, 256 + nc:].abs().max()))
     print("  coef      ", rel(t32_to_rows(coef_t, Mp, 32)[:M, 0], sg), " d_rgb", rel(t32_to_rows(drgb_t, Mp, 32)[:M, :3], d_rgb))
+    # ---- weight gradients: fused TN GEMMs vs the layer-wise path (defer_wgrad = 0)
+    grads_ref = Z(total)
+    work2 = E(nw)
+    _lib.call("pn_mlp_backward", M, rows_per_ray, R, nc, dbias, params.data_ptr(), wpack.data_ptr(), mean.data_ptr(),
+              cov.data_ptr(), enc.data_ptr(), venc.data_ptr(), acts.data_ptr(), masks.data_ptr(), rd.data_ptr(),
+              d_rgb.data_ptr(), d_den.data_ptr(), rsweep.data_ptr(), v.data_ptr(), d_mean.data_ptr(), grads_ref.data_ptr(),
+              work2.data_ptr(), 0, 0, 0, None, None, None, None, None, None, st(), None)
+
+    class Ev(ctypes.Structure):
+        _fields_ = [("M", ctypes.c_int64)] + [(k, ctypes.c_void_p) for k in
+                    ("enc_t", "acts_t", "drgb_t", "dhv_t", "d8_t", "delta_t", "rs_t", "edot_t", "tang_t", "coef_t")]
+    ev = Ev(M, enc_t.data_ptr(), acts_t.data_ptr(), drgb_t.data_ptr(), dhv_t.data_ptr(), d8_t.data_ptr(), delta_t.data_ptr(),
+            rs_t.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), coef_t.data_ptr())
+    grads_f = Z(total)
+    wfl = int(lib.pn_chain_wgrad_work_floats())
+    wk = E(wfl)
+    lib.pn_chain_wgrad.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int64, ctypes.c_void_p]
+    f_wg = lambda: _lib.check(lib.pn_chain_wgrad(1, ctypes.byref(ev), nc, planes, grads_f.data_ptr(), wk.data_ptr(), wfl, st()),
+                              "pn_chain_wgrad")
+    f_wg()
+    torch.cuda.synchronize()
+    names = [f"layers.{i}.{k}" for i in range(8) for k in ("w", "b")] + ["extra.w", "extra.b", "view.w", "view.b", "den.w", "col.w", "den.b", "col.b"]
+    offs = list(off) + [total]
+    order = sorted(range(24), key=lambda i: offs[i])
+    for n_, i in enumerate(order):
+        lo_, hi_ = offs[i], (offs[order[n_ + 1]] if n_ + 1 < 24 else total)
+        g, r = grads_f[lo_:hi_], grads_ref[lo_:hi_]
+        print(f"  grad {names[i]:12s} max-rel {rel(g, r):.2e}   norm-rel {float((g-r).norm()/r.norm().clamp_min(1e-30)):.2e}")
     if reps:
+        grads_f.zero_()
+        for name, fn, fl in (("wgrad", f_wg, 2 * (508160.0 * 2 + 611328.0 - 508160.0)),):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            print(f"  fused {name} {dt*1e3:.3f} ms ({M*fl/dt/1e12:.1f} TF fp32-equivalent)")
         for name, fn, fl in (("dgrad", f_dgrad, 2 * 508160.0), ("tangent", f_tan, 2 * 508160.0), ("backward", f_bwd, 2 * 611328.0)):
             fn(); torch.cuda.synchronize()
             t0 = time.perf_counter()
