@@ -42,33 +42,46 @@ def analytic_radiance(viewdirs, origins):
     return torch.clamp(torch.nn.functional.softplus(f), 0, 1000).float()
 
 
-def cpu_baseline(n_samples, rays_cpu, rgbs_cpu, env_cpu, b_cpu):
-    """The oracle (CPU restatement of the reference, 'faithful' = vmap(jacrev) normals like upstream) timed
-    on the host cores for ONE training step on a bounded sample of the same workload."""
+def cpu_baseline(n_samples, rays_cpu, rgbs_cpu, env_cpu, b_cpu, reps=3):
+    """The oracle (CPU restatement of the reference, 'faithful' = vmap(jacrev) normals like upstream) timed on the host
+    cores: one full-size warm-up step, then the median of `reps` training steps on `b_cpu` rays of the same synthetic
+    batch; the 'fast' (grad-of-sum normals) port once, so that the algorithmic and the hardware part of
+    the speed-up separate."""
     from oracle import pano_oracle as orc
     params = {k: v.clone().requires_grad_(True) for k, v in orc.init_params(4, 5).items()}
     opt = torch.optim.Adam(list(params.values()), lr=2e-4)
 
-    def step(rays, rgbs):
+    def step(rays, rgbs, mode):
         gen = torch.Generator().manual_seed(0)
         b, s = rays.origins.shape[0], n_samples + 1
         noise = dict(t_rand=torch.rand(b, s, generator=gen),
                      u_rand=torch.rand(b, s, generator=gen) * (1.0 / s - 1.2e-7),
                      env_rand=torch.rand(1, 11, generator=gen))
-        outs = orc.pano_forward(params, rays, env_cpu, num_samples=n_samples, noise=noise, normals_mode="faithful")
+        outs = orc.pano_forward(params, rays, env_cpu, num_samples=n_samples, noise=noise, normals_mode=mode)
         loss = orc.pano_loss(outs, rays.lossmult, rgbs)
         opt.zero_grad()
         loss.backward()
         opt.step()
 
-    sub = lambda n: (orc.Rays(*[x[:n] for x in rays_cpu]), rgbs_cpu[:n])
-    step(*sub(8))  # warm-up (thread pools, allocator)
+    rays = orc.Rays(*[x[:b_cpu] for x in rays_cpu])
+    rgbs = rgbs_cpu[:b_cpu]
+    step(rays, rgbs, "faithful")  # warm-up at full size (thread pools, allocator, functorch caches)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        step(rays, rgbs, "faithful")
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
     t0 = time.perf_counter()
-    step(*sub(b_cpu))
-    dt = time.perf_counter() - t0
-    out = {"value": b_cpu / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"1 train step (fwd+bwd+Adam, faithful vmap(jacrev) normals) on {b_cpu} rays x {n_samples}+"
-                     f"{n_samples} samples of the same synthetic batch, fp32, {dt:.1f} s"}
+    step(rays, rgbs, "fast")
+    t_fast = time.perf_counter() - t0
+    out = {"value": b_cpu / med, "unit": "rays/s", "cores": os.cpu_count(), "threads": torch.get_num_threads(),
+           "kind": "port",
+           "sample": f"median of {reps} train steps (fwd+bwd+Adam, faithful vmap(jacrev) normals) after 1 warm-up, each on "
+                     f"{b_cpu} rays x {n_samples}+{n_samples} samples of the same synthetic batch, fp32",
+           "samples_s": [round(t, 3) for t in times],
+           "fast_normals_port": {"value": b_cpu / t_fast, "unit": "rays/s", "seconds": round(t_fast, 3),
+                                 "note": "same step with grad-of-sum normals (one reverse sweep, the algorithm the HIP path uses)"}}
     cal = os.path.join(ROOT, "tests", "golden", "ref_cpu_timing.json")
     if os.path.exists(cal):  # port-vs-imported-reference speed ratio measured in the build container (8 vCPU)
         try:
@@ -88,11 +101,14 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--cpu-rays", type=int, default=192)
+    ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the full-panorama inference leg (N = 1 only)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
+    ap.add_argument("--mlp-mode", choices=("fused", "fused_bf16", "layerwise"), default=os.environ.get("PN_MLP_MODE", "fused"),
+                    help="fused: on-chip MLP chains, exact 3-term bf16 split (fp32 accuracy; default); fused_bf16: the same "
+                         "kernels with plain bf16 operands (BASELINE configs[1]); layerwise: one GEMM launch per layer")
     ap.add_argument("--gemm-mode", choices=("fp32", "split"), default=None,
                     help="fp32: exact fp32 MFMA (default); split: fp32-accurate 3-term bf16 split on the bf16 matrix cores "
                          "(default follows PN_GEMM_MODE)")
@@ -132,6 +148,25 @@ def main():
     _lib.load().pn_set_gemm_mode(1 if split else 0)
     # price the NT GEMMs against the matrix-core rate of the instruction they use: fp32 MFMA, or bf16 MFMA / 6 products
     peak_nt = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
+    fused = args.mlp_mode != "layerwise"
+    # fused chains: v_mfma_f32_32x32x16_bf16, six products per fp32-equivalent product (split) or one (plain bf16)
+    peak_chain = PEAK_BF16_MFMA_TFLOPS / 6.0 if args.mlp_mode == "fused" else PEAK_BF16_MFMA_TFLOPS
+    CLASSES = ((0, "k_gemm_nt"), (1, "k_gemm_tn"), (2, "k_chain_fwd"), (3, "k_chain_dgrad"), (4, "k_chain_tangent"),
+               (5, "k_chain_bwd"), (6, "k_chain_wgrad"))
+
+    def read_prof():
+        res = {}
+        for cls, name in CLASSES:
+            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+            if n.value:
+                res[name] = (ms.value, n.value, fl.value)
+        return res
+
+    def peak_of(name):
+        if name.startswith("k_chain"):
+            return peak_chain
+        return peak_nt if name == "k_gemm_nt" else PEAK_F32_MFMA_TFLOPS
 
     # ---- synthetic scene: 3 identity-rotation cameras, analytic HDR radiance, rays made by K1
     torch.manual_seed(4)
@@ -150,6 +185,7 @@ def main():
 
     model = pn.PanoMipNeRF(num_samples=args.samples, rgb_activation="softplus", rgb_padding=0,
                            mlp_num_density_channels=5, num_env_samples=10).to(dev)
+    model.mlp_mode = args.mlp_mode
     model.overlap_weight_grads = args.overlap == "on"
     if world > 1:  # identical replicas
         dist.broadcast(model.mlp.flat_params(), 0)
@@ -249,11 +285,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     used_graph = graph is not None
-    prof = {}
-    for cls, name in ((0, "k_gemm_nt"), (1, "k_gemm_tn")):
-        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-        _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
-        prof[name] = (ms.value, n.value, fl.value)
+    prof = read_prof()
     _lib.load().pn_prof_enable(0)
     if not prof_live:  # graph mode: measure the per-launch figures on 2 eager steps right after the timed region
         eager_graph, graph = graph, None
@@ -262,10 +294,7 @@ def main():
         for i in range(2):
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
-        for cls, name in ((0, "k_gemm_nt"), (1, "k_gemm_tn")):
-            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-            _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
-            prof[name] = (ms.value, n.value, fl.value)
+        prof = read_prof()
         _lib.load().pn_prof_enable(0)
         graph = None
     # the same kernels with the side stream off: per-launch durations without time-sharing (not part of `value`)
@@ -278,11 +307,9 @@ def main():
         for i in range(2):
             step(args.warmup + args.steps + 1 + i, local=True)
         torch.cuda.synchronize()
-        for cls, name in ((0, "k_gemm_nt"), (1, "k_gemm_tn")):
-            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-            _lib.load().pn_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
-            iso[name] = {"avg_launch_us": 1e3 * ms.value / max(n.value, 1), "tflops": fl.value / max(ms.value, 1e-9) / 1e9,
-                         "frac": fl.value / max(ms.value, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS}
+        for name, (ms_, n_, fl_) in read_prof().items():
+            iso[name] = {"avg_launch_us": 1e3 * ms_ / max(n_, 1), "tflops": fl_ / max(ms_, 1e-9) / 1e9,
+                         "frac": fl_ / max(ms_, 1e-9) / 1e9 / peak_of(name)}
         _lib.load().pn_prof_enable(0)
         model.overlap_weight_grads = args.overlap == "on"
     if world > 1:
@@ -299,7 +326,7 @@ def main():
         avg_us = 1e3 * ms / max(n, 1)
         achieved = fl / max(ms, 1e-9) / 1e9  # TFLOP/s  (FLOP / ms / 1e9)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json" if fused else "r01_pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
@@ -309,7 +336,8 @@ def main():
             "metric": "rays/sec (train step)", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (3xbf16 split products, fp32 accumulate)" if split else "f32", "data": "synthetic",
+            "dtype": ("f32 (3xbf16 split products, fp32 accumulate)" if (split or args.mlp_mode == "fused") else
+                      ("bf16 (fp32 accumulate)" if args.mlp_mode == "fused_bf16" else "f32")), "data": "synthetic",
             "config": {"workload": f"panonerf.yaml train step, synthetic {args.height}x{args.width} pano pool x3 cams, "
                                    f"{args.samples} coarse + {args.samples} fine samples, 10x10 env-light rays, "
                                    f"surface+chrom+ort loss, Adam; global batch {args.global_batch} rays "
@@ -319,11 +347,18 @@ def main():
                        "launch": "hip-graph replay" if used_graph else "eager",
                        "schedule": (f"{n_streams} concurrent sub-batches of {(hi - lo + n_streams - 1) // n_streams} rays on "
                                     f"{n_streams} HIP streams per GPU" if n_streams > 1 else "one chain per GPU"),
-                       "gemm_mode": "split: x = h + m + l (bf16), six partial products on v_mfma_f32_32x32x16_bf16, fp32 "
-                                    "accumulate; weight gradients on fp32 MFMA" if split else "exact fp32 MFMA"},
+                       "mlp_mode": args.mlp_mode,
+                       "gemm_mode": ("fused on-chip chains (one kernel per forward / reverse sweep / tangent sweep / "
+                                     "backward pass, activations in registers, weights by LDS-DMA ring) + T32 weight-gradient "
+                                     "GEMMs, " + ("x = h + m + l (bf16), six partial products on v_mfma_f32_32x32x16_bf16, "
+                                                  "fp32 accumulate (fp32 accuracy)" if args.mlp_mode == "fused" else
+                                                  "plain bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate"))
+                                    if fused else
+                                    ("split: x = h + m + l (bf16), six partial products on v_mfma_f32_32x32x16_bf16, fp32 "
+                                     "accumulate; weight gradients on fp32 MFMA" if split else "exact fp32 MFMA")},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
-                         "peak": peak_nt if dom == "k_gemm_nt" else PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / (peak_nt if dom == "k_gemm_nt" else PEAK_F32_MFMA_TFLOPS),
+                         "peak": peak_of(dom),
+                         "unit": "TFLOP/s", "frac": achieved / peak_of(dom),
                          "traffic": traffic,
                          "avg_launch_us": avg_us, "launches": n,
                          "measured": "HIP events around every GEMM launch " + ("during the timed region" if prof_live else
@@ -334,15 +369,23 @@ def main():
                                   "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the "
                                   "same kernels in 2 extra steps with the side stream off.  " if args.overlap == "on" else
                                   "all launches on one stream (no time sharing between kernels).  ") +
-                                 "`peak` is the 2.4 GHz datasheet figure; under the power cap the same k_gemm_nt binary runs "
-                                 "126 TF on zero/constant operands and 101 TF on N(0,1) operands (tools/bench_clock.py, "
-                                 "profiles/r01_clock_vs_data.txt) and sustains a 2.10 GHz shader clock inside its K loop "
-                                 "(tools/trace_nt.py, profiles/r01_nt_phase_trace_K256.txt), i.e. 137.5 TF are available",
+                                 ("`achieved` and `peak` are fp32-equivalent: algorithmic 2*M*N*K FLOPs per launch against the "
+                                  "dense bf16 MFMA peak (2.5 PF) divided by the six partial products per fp32 product"
+                                  if args.mlp_mode == "fused" else
+                                  ("`peak` is the dense bf16 MFMA figure (2.5 PF)" if args.mlp_mode == "fused_bf16" else
+                                   "`peak` is the 2.4 GHz datasheet figure; under the power cap the same k_gemm_nt binary runs "
+                                   "126 TF on zero/constant operands and 101 TF on N(0,1) operands (tools/bench_clock.py, "
+                                   "profiles/r01_clock_vs_data.txt) and sustains a 2.10 GHz shader clock inside its K loop "
+                                   "(tools/trace_nt.py, profiles/r01_nt_phase_trace_K256.txt), i.e. 137.5 TF are available")),
                          "isolated": iso,
                          "flop_per_launch": fl / max(n, 1),
-                         "other": {k: {"total_ms": v[0], "launches": v[1],
-                                       "tflops": v[2] / max(v[0], 1e-9) / 1e9} for k, v in prof.items()},
-                         "end_to_end_frac": value / world * flop_per_ray_step(args.samples) / (PEAK_F32_MFMA_TFLOPS * 1e12)},
+                         "other": {k: {"total_ms": v[0], "launches": v[1], "avg_launch_us": 1e3 * v[0] / max(v[1], 1),
+                                       "tflops": v[2] / max(v[0], 1e-9) / 1e9,
+                                       "frac": v[2] / max(v[0], 1e-9) / 1e9 / peak_of(k)} for k, v in prof.items()},
+                         "end_to_end_frac": value / world * flop_per_ray_step(args.samples) /
+                                            ((peak_chain if fused else PEAK_F32_MFMA_TFLOPS) * 1e12),
+                         "end_to_end_frac_of_fp32_mfma_peak": value / world * flop_per_ray_step(args.samples) /
+                                                              (PEAK_F32_MFMA_TFLOPS * 1e12)},
             "psnr_batch_db": psnr, "loss": float(loss),
         }
         if world == 1 and not args.no_inference:

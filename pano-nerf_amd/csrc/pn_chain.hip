@@ -1230,7 +1230,7 @@ static int pack_both(int nc, const float* params, unsigned char* out, hipStream_
 }
 
 template <typename K, typename A>
-static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s);
+static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s, int cls, double flops);
 
 static int g_chain_cus = 0;
 static int chain_grid(int64_t nst) {
@@ -1244,7 +1244,8 @@ static int chain_grid(int64_t nst) {
 }
 
 template <typename K, typename A>
-static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s) {
+static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s, int cls, double flops) {
+    PnProfScope prof(cls, flops, s);
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return PN_ERR_HIP;
@@ -1254,13 +1255,16 @@ static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, c
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
-#define LAUNCH_CHAIN(KERNEL, planes, nst, args, s)                                                      \
-    do {                                                                                                \
-        static bool done3 = false, done1 = false;                                                       \
-        if ((planes) == 3) return launch_chain(KERNEL<3>, Cfg<3>::LDS_BYTES, done3, nst, args, s);      \
-        if ((planes) == 1) return launch_chain(KERNEL<1>, Cfg<1>::LDS_BYTES, done1, nst, args, s);      \
-        return PN_ERR_UNSUPPORTED;                                                                      \
+#define LAUNCH_CHAIN(KERNEL, planes, nst, args, s, cls, flops)                                                   \
+    do {                                                                                                        \
+        static bool done3 = false, done1 = false;                                                               \
+        if ((planes) == 3) return launch_chain(KERNEL<3>, Cfg<3>::LDS_BYTES, done3, nst, args, s, cls, flops);  \
+        if ((planes) == 1) return launch_chain(KERNEL<1>, Cfg<1>::LDS_BYTES, done1, nst, args, s, cls, flops);  \
+        return PN_ERR_UNSUPPORTED;                                                                              \
     } while (0)
+// algorithmic MACs x 2 per sample row: forward / data-gradient chain, and the trunk-only sweeps
+static double flops_mlp(int nc) { return 2.0 * ((nc == 5 ? 611328.0 : 610304.0)); }
+static const double kFlopsSweep = 1016320.0;
 
 
 // ---- weight gradients of one training step -------------------------------------------------------------------
@@ -1298,12 +1302,17 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     a.slab_stride = stride;
     a.bias = j.dbias != nullptr;
     const dim3 grid((unsigned)nsplit);
+    double rows = 0;
+    for (int i = 0; i < j.nseg; ++i) rows += 16.0 * (double)j.seg[i].nhalf;
+    {
+    PnProfScope prof(6, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone (not the slab reduction)
     switch (j.cfg) {
         case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a); break;
         case 1: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 8, 1>), grid, dim3(512), 0, s, a); break;
         case 2: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 9, 4, 1>), grid, dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 2, 1, 4>), grid, dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 1, 1, 4>), grid, dim3(256), 0, s, a); break;
+    }
     }
     PN_CHECK_LAUNCH();
     float* scratch = work + nsplit * stride;
@@ -1349,7 +1358,7 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     a.pack = (const unsigned char*)pack;
     a.mean = mean; a.cov = cov; a.viewdirs = viewdirs;
     a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
-    LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, a, (hipStream_t)stream);
+    LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, a, (hipStream_t)stream, 2, (double)M * flops_mlp(nc));
 }
 
 /* d sigma / d mean by one reverse sweep (see k_chain_dgrad).  rs_t: T32 [8][Mp*256] (r_0..r_7, kept for the second-order
@@ -1375,7 +1384,7 @@ int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, con
     a.masks = masks; a.raw_den = raw_den; a.mean = mean; a.cov = cov;
     a.wd0 = params + pn_layout(nc).wd;
     a.vec_t = rs_t; a.out3 = grad_mean;
-    LAUNCH_CHAIN(k_chain_dgrad, planes, a.nst, a, (hipStream_t)stream);
+    LAUNCH_CHAIN(k_chain_dgrad, planes, a.nst, a, (hipStream_t)stream, 3, (double)M * kFlopsSweep);
 }
 
 /* forward-mode tangent sweep along v (see k_chain_tangent): edot_t T32 [Mp*96], tang_t T32 [8][Mp*256], sdot [M]. */
@@ -1395,7 +1404,7 @@ int pn_chain_tangent(int64_t M, int nc, int planes, const float* params, const v
     a.masks = masks; a.mean = mean; a.cov = cov; a.v = v;
     a.wd0 = params + pn_layout(nc).wd;
     a.vec_t = tang_t; a.edot_t = edot_t; a.sdot = sdot;
-    LAUNCH_CHAIN(k_chain_tangent, planes, a.nst, a, (hipStream_t)stream);
+    LAUNCH_CHAIN(k_chain_tangent, planes, a.nst, a, (hipStream_t)stream, 4, (double)M * kFlopsSweep);
 }
 
 /* backward chain (see k_chain_bwd).  sdot / coef_t: second-order path (both or neither); d_mean nullable. */
@@ -1422,7 +1431,7 @@ int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const v
     a.masks = masks; a.raw_den = raw_den; a.d_rgb = d_raw_rgb; a.d_den = d_raw_den; a.sdot = sdot;
     a.mean = mean; a.cov = cov;
     a.drgb_t = drgb_t; a.dhv_t = dhv_t; a.d8_t = d8_t; a.delta_t = delta_t; a.coef_t = coef_t; a.d_mean = d_mean;
-    LAUNCH_CHAIN(k_chain_bwd, planes, a.nst, a, (hipStream_t)stream);
+    LAUNCH_CHAIN(k_chain_bwd, planes, a.nst, a, (hipStream_t)stream, 5, (double)M * (flops_mlp(nc) - (d_mean ? 0.0 : 2.0 * 2 * 96 * 256)));
 }
 
 

@@ -65,6 +65,14 @@ int64_t pn_tn_work_floats(int64_t Mtotal, int N1, int N2);
 int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, int ldc, int accumulate, float* work,
                       int64_t work_avail, hipStream_t s);
 
+// launch timing (pn_prof_enable / pn_prof_read): bracket a launch with HIP events on its stream.  Classes: 0 k_gemm_nt,
+// 1 k_gemm_tn, 2 k_chain_fwd, 3 k_chain_dgrad, 4 k_chain_tangent, 5 k_chain_bwd, 6 k_chain_wgrad
+struct PnProfScope {
+    void* impl;
+    PnProfScope(int cls, double flops, hipStream_t s);
+    ~PnProfScope();
+};
+
 // bf16 split planes of the weight blocks (pn_gemm.hip keeps the registry; pn_mlp.hip fills the planes)
 void pn_register_planes(int which, const float* fbase, int64_t nfloats, const unsigned short* planes);
 

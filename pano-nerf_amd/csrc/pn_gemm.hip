@@ -30,8 +30,9 @@ static bool g_prof_on = false;
 static int g_dbg = 0;  // ablation switches (tools/bench_gemm.py): pn_prof_enable(on | dbg << 8)
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_free_events;
-static double g_prof_ms[2] = {0, 0}, g_prof_flops[2] = {0, 0};
-static int64_t g_prof_n[2] = {0, 0};
+#define PN_PROF_CLASSES 8
+static double g_prof_ms[PN_PROF_CLASSES] = {0}, g_prof_flops[PN_PROF_CLASSES] = {0};
+static int64_t g_prof_n[PN_PROF_CLASSES] = {0};
 
 static hipEvent_t prof_event() {
     if (!g_free_events.empty()) {
@@ -60,6 +61,9 @@ struct ProfScope {
         if (live && hipEventRecord(r.e1, s) == hipSuccess) g_prof.push_back(r);
     }
 };
+// the same bracket for the kernels of other translation units (pn_chain.hip)
+PnProfScope::PnProfScope(int cls, double flops, hipStream_t s) : impl(new ProfScope(cls, flops, s)) {}
+PnProfScope::~PnProfScope() { delete static_cast<ProfScope*>(impl); }
 static void prof_drain() {
     for (auto& r : g_prof) {
         float ms = 0.f;
@@ -77,7 +81,7 @@ extern "C" int pn_prof_enable(int on) {
     prof_drain();
     g_prof_on = (on & 1) != 0;
     g_dbg = on >> 8;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PN_PROF_CLASSES; ++i) {
         g_prof_ms[i] = 0;
         g_prof_flops[i] = 0;
         g_prof_n[i] = 0;
@@ -85,7 +89,7 @@ extern "C" int pn_prof_enable(int on) {
     return PN_OK;
 }
 extern "C" int pn_prof_read(int cls, double* total_ms, int64_t* launches, double* flops) {
-    if (cls < 0 || cls > 1) return PN_ERR_BAD_SHAPE;
+    if (cls < 0 || cls >= PN_PROF_CLASSES) return PN_ERR_BAD_SHAPE;
     prof_drain();
     if (total_ms) *total_ms = g_prof_ms[cls];
     if (launches) *launches = g_prof_n[cls];
