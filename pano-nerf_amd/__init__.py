@@ -9,6 +9,7 @@ Public surface (mirrors the reference's names):
     render_image                  systems/panonerf_system.py:133-192
     metrics, io_exr               utils/metrics.py:210-397 (calc_* / calc_ws_*), utils/io_exr.py:6-47
     concurrent_step               one training step as concurrent sub-batches on separate HIP streams
+    install                       register PanoMipNeRF / MipNeRF under the reference's import paths (zero-edit drop-in)
 """
 __version__ = "0.1.0"
 
@@ -20,3 +21,4 @@ from .optim import FlatAdam, mip_lr  # noqa
 from .renderer import render_image  # noqa
 from . import metrics, io_exr  # noqa
 from .parallel import concurrent_step  # noqa
+from .install import install, uninstall  # noqa

@@ -1025,9 +1025,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < LX; ++i) bsum[i] = 0.f;
 
-    f32x4 xr[LX], yr[LY];
-    float bw = 0.f;  // bias weight of the half block held in xr
-    auto load = [&](int64_t h) {
+    // two register sets: the loads of half block h + 2 are issued when h's set has been staged, so they have two half
+    // blocks of MFMA time to land (one workgroup per CU: nothing else hides the HBM latency)
+    f32x4 xr[2][LX], yr[2][LY];
+    float bw[2] = {0.f, 0.f};  // bias weight of the half block held in each set
+    auto load = [&](int64_t h, int set) {
         int sg = 0;
         int64_t hb = h;
 #pragma unroll
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
                 sg = i + 1;
             }
         const WSeg& S = a.seg[sg];
-        bw = S.bias ? 1.f : 0.f;
+        bw[set] = S.bias ? 1.f : 0.f;
         const int64_t blk = hb >> 1;
         const int half = (int)(hb & 1);
         const float* xb = S.X + blk * ((int64_t)S.FX * 32) + half * 16;
@@ -1045,12 +1047,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
-            if (CX % NTH == 0 || idx < CX) xr[i] = *reinterpret_cast<const f32x4*>(xb + (idx >> 2) * 32 + (idx & 3) * 4);
+            if (CX % NTH == 0 || idx < CX) xr[set][i] = *reinterpret_cast<const f32x4*>(xb + (idx >> 2) * 32 + (idx & 3) * 4);
         }
 #pragma unroll
         for (int i = 0; i < LY; ++i) {
             const int idx = tid + NTH * i;
-            if (CY % NTH == 0 || idx < CY) yr[i] = *reinterpret_cast<const f32x4*>(yb + (idx >> 2) * 32 + (idx & 3) * 4);
+            if (CY % NTH == 0 || idx < CY) yr[set][i] = *reinterpret_cast<const f32x4*>(yb + (idx >> 2) * 32 + (idx & 3) * 4);
         }
     };
     auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v) {
@@ -1075,48 +1077,57 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             *reinterpret_cast<bf16x4*>(plane0 + 2 * pstride + o) = lv;
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, int set) {
         unsigned short* xs = smem + buf * BUF;
         unsigned short* ys = xs + NP * PX;
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
             if (CX % NTH == 0 || idx < CX) {
-                put(xs, PX, idx, xr[i]);
-                bsum[i] += bw * ((xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]));
+                put(xs, PX, idx, xr[set][i]);
+                bsum[i] += bw[set] * ((xr[set][i][0] + xr[set][i][1]) + (xr[set][i][2] + xr[set][i][3]));
             }
         }
 #pragma unroll
         for (int i = 0; i < LY; ++i) {
             const int idx = tid + NTH * i;
-            if (CY % NTH == 0 || idx < CY) put(ys, PY, idx, yr[i]);
+            if (CY % NTH == 0 || idx < CY) put(ys, PY, idx, yr[set][i]);
         }
     };
     const int fr = lane & 31, fh = lane >> 5;
     auto frag = [&](const unsigned short* plane, int feature) {
         return *reinterpret_cast<const bf16x8*>(plane + feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3));
     };
+    auto compute = [&](int buf) {
+        const unsigned short* xs = smem + buf * BUF;
+        const unsigned short* ys = xs + NP * PX;
+        BFrag<NP> af[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) af[i].p[p] = frag(xs + p * PX, 32 * (wm * TM + i) + fr);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            BFrag<NP> bf;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) bf.p[p] = frag(ys + p * PY, 32 * (wn * TN + j) + fr);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split<NP>(af[i], bf, acc[i][j]);
+        }
+    };
     if (h0 < h1) {
-        load(h0);
-        for (int64_t h = h0; h < h1; ++h) {
-            const int buf = (int)((h - h0) & 1);
-            stage(buf);
+        load(h0, 0);
+        if (h0 + 1 < h1) load(h0 + 1, 1);
+        for (int64_t h = h0; h < h1; h += 2) {  // two half blocks per trip: static register-set / buffer indices
+            stage(0, 0);
             __syncthreads();
-            if (h + 1 < h1) load(h + 1);
-            const unsigned short* xs = smem + buf * BUF;
-            const unsigned short* ys = xs + NP * PX;
-            BFrag<NP> af[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) af[i].p[p] = frag(xs + p * PX, 32 * (wm * TM + i) + fr);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                BFrag<NP> bf;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) bf.p[p] = frag(ys + p * PY, 32 * (wn * TN + j) + fr);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split<NP>(af[i], bf, acc[i][j]);
+            if (h + 2 < h1) load(h + 2, 0);
+            compute(0);
+            if (h + 1 < h1) {
+                stage(1, 1);
+                __syncthreads();
+                if (h + 3 < h1) load(h + 3, 1);
+                compute(1);
             }
         }
     }
