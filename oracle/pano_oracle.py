@@ -248,18 +248,49 @@ def init_params(seed, num_density_channels=5):
     return params
 
 
+# Test hook (not part of the reference): a queue of ReLU gate decisions, one [9, M, 256] boolean tensor per mlp_forward
+# call (h0..h7, view hidden in the first 128 columns).  With gates forced, relu(z) becomes z * gate, so that two
+# implementations can be compared on IDENTICAL gate decisions: a ReLU whose pre-activation is ~1e-7 flips under any fp32
+# summation order and makes parameter gradients (not values) discontinuous, which no pointwise tolerance survives.
+_FORCED_GATES = None
+
+
+class forced_gates:
+    def __init__(self, gates):
+        self.gates = list(gates)
+
+    def __enter__(self):
+        global _FORCED_GATES
+        _FORCED_GATES = list(self.gates)
+        return self
+
+    def __exit__(self, *a):
+        global _FORCED_GATES
+        left, _FORCED_GATES = _FORCED_GATES, None
+        if a[0] is None:
+            assert not left, f"{len(left)} forced gate sets were not consumed"
+
+
+def _act(z, gates, slot):
+    if gates is None:
+        return torch.relu(z)
+    g = gates[slot][..., :z.shape[-1]].reshape(z.shape).to(z.dtype)
+    return z * g
+
+
 def mlp_forward(p, enc, viewenc, skip=4, depth=8):
     """models/pano_mip_nerf.py:95-114.  enc [B,N,96], viewenc [B,27]."""
+    gates = _FORCED_GATES.pop(0) if _FORCED_GATES else None
     x = enc
     for i in range(depth):
-        x = torch.relu(torch.nn.functional.linear(x, p[f"layers.{i}.0.weight"], p[f"layers.{i}.0.bias"]))
+        x = _act(torch.nn.functional.linear(x, p[f"layers.{i}.0.weight"], p[f"layers.{i}.0.bias"]), gates, i)
         if i % skip == 0 and i > 0:
             x = torch.cat([x, enc], -1)
     raw_density = torch.nn.functional.linear(x, p["density_layer.weight"], p["density_layer.bias"])
     bott = torch.nn.functional.linear(x, p["extra_layer.weight"], p["extra_layer.bias"])
     ve = viewenc[:, None, :].expand(-1, enc.shape[1], -1)
-    x = torch.relu(torch.nn.functional.linear(torch.cat([bott, ve], -1),
-                                              p["view_layers.0.0.weight"], p["view_layers.0.0.bias"]))
+    x = _act(torch.nn.functional.linear(torch.cat([bott, ve], -1),
+                                        p["view_layers.0.0.weight"], p["view_layers.0.0.bias"]), gates, 8)
     raw_rgb = torch.nn.functional.linear(x, p["color_layer.weight"], p["color_layer.bias"])
     return raw_rgb, raw_density
 

@@ -37,3 +37,36 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     scale = max(float(np.max(np.abs(b))), 1e-30)
     return float(np.max(np.abs(a - b)) / scale)
+
+
+FIRST_ORDER_TENSORS = ("extra_layer", "view_layers", "color_layer")
+
+
+def check_flat_grad_per_tensor(flat_grad, ref_by_name, nc, second_order):
+    """Every tensor of the flat gradient block against reference gradients {state-dict key: tensor or None}.
+    Tensors with no trunk ReLU gate below them (extra / view / colour layers; the density head unless the normals are in
+    the loss): max |err| <= 1e-4 of the tensor max over all entries.  The others sit upstream of ReLU gates, whose
+    flips (pre-activation ~1e-7, any fp32 summation order) make the gradient discontinuous — the reference's fp32 run
+    differs from its own fp64 run by up to 2.8e-3 of the tensor max there: median <= 2e-4, >= 90 % of the entries
+    <= 1e-3, relative L2 <= 5e-3 (tests/test_gpu_grads.py has the pointwise, gate-consistent form)."""
+    from pano_nerf_amd.mlp import ORDER, param_layout
+    offs, total = param_layout(nc)
+    order = sorted(ORDER, key=lambda k: offs[k])
+    got_all = np.asarray(flat_grad, dtype=np.float64).reshape(-1)
+    assert got_all.size == total and np.isfinite(got_all).all()
+    for i, k in enumerate(order):
+        lo, hi = offs[k], offs[order[i + 1]] if i + 1 < len(order) else total
+        got = got_all[lo:hi]
+        r = ref_by_name.get(k)
+        ref = np.zeros_like(got) if r is None else np.asarray(r, dtype=np.float64).reshape(-1)
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        err = np.abs(got - ref) / scale
+        if float(np.abs(ref).max()) == 0.0:
+            assert float(np.abs(got).max()) <= 1e-12, (k, "expected a zero gradient")
+        elif k.startswith(FIRST_ORDER_TENSORS) or (not second_order and k.startswith("density_layer")):
+            assert float(err.max()) <= 1e-4, (k, "max", float(err.max()))
+        else:  # upstream of ReLU gates: a flipped gate (pre-activation ~1e-7) moves the whole tensor by a rank-1 update
+            assert float(np.median(err)) <= 2e-4, (k, "median", float(np.median(err)))
+            assert float(np.mean(err <= 1e-3)) >= 0.9, (k, "fraction within 1e-3", float(np.mean(err <= 1e-3)))
+            rl2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+            assert rl2 <= 5e-3, (k, "relative L2", rl2)

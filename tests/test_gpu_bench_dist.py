@@ -28,6 +28,7 @@ def test_two_rank_bench_flow(graph):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong"
     assert out["config"]["rays_per_gpu"] == 128 and out["value"] > 0
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert out["roofline"]["kernel"].startswith("k_chain")
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
 
 
@@ -39,3 +40,14 @@ def test_two_rank_render_matches_single_rank():
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     assert "RENDER_DIST_OK" in res.stdout
+
+
+def test_ddp_wrapped_module_trains():
+    """'Lightning DDP wraps the module as usual' — DistributedDataParallel + torch Adam over the flat-view
+    parameters: parameters stay flat, the packed weights follow optimizer.step(), replicas stay bit-equal."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29521", os.path.join(ROOT, "tests", "_ddp_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert "DDP_OK" in res.stdout

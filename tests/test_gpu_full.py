@@ -54,8 +54,14 @@ def check_tuple(outs, g, prefix, names, g64=None):
             if nme in LOOSE and lvl == 1:
                 assert e < 5e-2, (key, e)
                 if got.ndim > 0:
-                    med = float(np.median(np.abs(got - g[key]) / (np.abs(g[key]) + 1e-6)))
+                    rel = np.abs(got - g[key]) / (np.abs(g[key]) + 1e-6)
+                    med = float(np.median(rel))
                     assert med < 1e-4, (key, med)
+                    # >= 99 % of the elements within 1e-3.  The goldens hold 16 / 64 rays, where 1 % is less
+                    # than one ray: one ray (3 elements) may sit on a flipped ReLU gate, as one does in the reference's
+                    # own fp32-vs-fp64 comparison on these batches
+                    bad = int(np.sum(np.abs(got - g[key]) > 1e-3 * max(float(np.max(np.abs(g[key]))), 1e-12)))
+                    assert bad <= max(3, int(0.01 * got.size)), (key, bad, got.size)
                 k64 = f"val64/l1/{nme}"
                 if g64 is not None and k64 in g64 and prefix == "val" and got.ndim > 0:
                     # vs the reference's own fp64 run: a ReLU gate whose pre-activation is ~1e-7 can flip under

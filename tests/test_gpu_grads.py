@@ -1,0 +1,218 @@
+"""Parameter-gradient parity at the 1e-4 contract, against FULL gradients of the imported reference (fp32 run and
+fp64 run; tests/golden/make_grad_golden.py), for every MLP mode of the HIP path.
+
+Three tests:
+  * tensors with no trunk ReLU gate below them (extra_layer / view_layers / color_layer; the density head when the
+    normals are not in the loss): max |err| over ALL entries <= 1e-4 of the tensor's max, against the reference's fp32
+    gradients;
+  * tensors upstream of ReLU gates (the trunk; the density head with normals in the loss): a gate whose pre-activation
+    is ~1e-7 flips under any fp32 summation order and the GRADIENT jumps (the value does not) — the reference's own
+    fp32 run differs from its fp64 run by up to 2.8e-3 of the tensor max there, in first order already.  Gated on
+    median <= 1e-4, >= 99 % of the entries <= 1e-3 (wherever the reference's own fp32-vs-fp64 comparison meets that),
+    relative L2 <= 5e-3, and <= 2x the reference-fp32's own error against the fp64 gradients (check_second_order);
+  * the strong form, test_gate_consistent_gradients_pointwise: with the gate decisions of the GPU kernels forced into
+    the oracle, EVERY entry of EVERY tensor (second order included) agrees to 1e-4 of the tensor max.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pano_oracle as orc
+from test_gpu_full import dev, env_of, make_pano, rays_of, to_dev
+
+pytestmark = pytest.mark.gpu
+CASES = ["B64_N32", "B16_N128"]
+MODES = ["fused", "layerwise"]
+FIRST_ORDER = ("extra_layer", "view_layers", "color_layer")
+
+
+def tensors(nc):
+    from pano_nerf_amd.mlp import ORDER, param_layout
+    offs, total = param_layout(nc)
+    order = sorted(ORDER, key=lambda k: offs[k])
+    return [(k, offs[k], offs[order[i + 1]] if i + 1 < len(order) else total) for i, k in enumerate(order)]
+
+
+def check_first_order(name, got, ref):
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    e = float(np.abs(got - ref).max()) / scale
+    assert e <= 1e-4, (name, e)
+
+
+def check_second_order(name, got, ref32, ref64):
+    """Tensors upstream of ReLU gates.  Against the reference's fp32 gradients: median <= 1e-4, >= 99 % of the entries
+    <= 1e-3, relative L2 error <= 5e-3.  Against its fp64 gradients: our error is compared with the reference-fp32's own
+    error at the median and the 99 % quantile (<= 2x) — with a floor of 5e-5, because on these 16 / 64-ray batches both
+    errors are set by a Poisson-distributed handful of gate flips (0-3 per run), not by arithmetic: the reference's fp32
+    run itself differs from its fp64 run by up to 2.8e-3 of the tensor max on FIRST-order gradients
+    (tests/golden/grads_mip_B16_N128.npz, train mode, layers.6.0.weight)."""
+    scale = max(float(np.abs(ref64).max()), 1e-30)
+    err = np.abs(got - ref32) / scale
+    assert float(np.median(err)) <= 1e-4, (name, "median", float(np.median(err)))
+    assert float(np.linalg.norm(got - ref32) / max(np.linalg.norm(ref32), 1e-30)) <= 5e-3, (name, "relative L2")
+    ours = np.abs(got - ref64) / scale
+    theirs = np.abs(ref32 - ref64) / scale
+    # ">= 99 % of the entries within 1e-3" wherever the reference meets it against its own fp64 run; where a gate flip
+    # of the reference's own fp32 run already moves more than 0.1 % of a tensor's entries past 1e-3 (a 256-entry bias
+    # under one flipped sample), the same slack is granted plus one more flip's worth
+    frac_ours, frac_theirs = float(np.mean(err <= 1e-3)), float(np.mean(theirs <= 1e-3))
+    need = 0.99 if frac_theirs >= 0.999 else max(0.5, frac_theirs - 0.3)
+    assert frac_ours >= need, (name, "fraction within 1e-3", frac_ours, frac_theirs)
+    for q in (0.5, 0.99):
+        a, b = float(np.quantile(ours, q)), float(np.quantile(theirs, q))
+        assert a <= 2 * b + 5e-5, (name, f"q{q}", a, b)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", CASES)
+def test_pano_full_gradients(golden, case, mode):
+    import pano_nerf_amd as pn
+    g, s, gg = golden("pano_full_" + case), golden("stages_" + case), golden("grads_pano_" + case)
+    N = s["t_det"].shape[1] - 1
+    rays, env = to_dev(rays_of(s)), to_dev(env_of(golden))
+    model = make_pano(N)
+    model.mlp_mode = mode
+    model.noise_override = dict(t_rand=torch.from_numpy(g["train_t_rand"]), u_rand=torch.from_numpy(g["train_u_rand"]),
+                                env_rand=torch.from_numpy(g["train_env_rand"]))
+    outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    loss, _ = pn.pano_loss(outs, rays.lossmult, torch.from_numpy(s["rgbs"]).to(dev()))
+    assert abs(float(loss) - float(gg["loss32"])) < 1e-4 * abs(float(gg["loss32"]))
+    loss.backward()
+    got = model.mlp.last_flat_grad.detach().cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    g32, g64 = gg["g32"].astype(np.float64), gg["g64"].astype(np.float64)
+    for k, lo, hi in tensors(5):
+        if k.startswith(FIRST_ORDER):
+            check_first_order(k, got[lo:hi], g32[lo:hi])
+        else:
+            check_second_order(k, got[lo:hi], g32[lo:hi], g64[lo:hi])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", CASES)
+def test_mip_full_gradients(golden, case, mode):
+    import pano_nerf_amd as pn
+    g, s, gg = golden("mip_full_" + case), golden("stages_" + case), golden("grads_mip_" + case)
+    N = s["t_det"].shape[1] - 1
+    rays = to_dev(rays_of(s))
+    model = make_pano(N, nc=1)
+    model.mlp_mode = mode
+    for tag, use_ort in (("train", False), ("trainort", True)):
+        model.noise_override = dict(t_rand=torch.from_numpy(g[tag + "_t_rand"]), u_rand=torch.from_numpy(g[tag + "_u_rand"]))
+        for p in model.mlp.parameters():
+            p.grad = None
+        outs = model(rays=rays, randomized=True, white_bkgd=False, use_ort_loss=use_ort)
+        loss, _ = pn.mip_loss(outs, rays.lossmult, torch.from_numpy(s["rgbs"]).to(dev()), use_ort=use_ort)
+        loss.backward()
+        got = model.mlp.last_flat_grad.detach().cpu().numpy().astype(np.float64)
+        g32 = gg[tag + "_g32"].astype(np.float64)
+        for k, lo, hi in tensors(1):
+            # pointwise 1e-4 for the tensors no trunk gate sits below; the trunk (and, with the orientation loss, the
+            # density head) is upstream of ReLU gates whose flips make the GRADIENT discontinuous even in first order
+            if k.startswith(FIRST_ORDER) or (not use_ort and k.startswith("density_layer")):
+                check_first_order(f"{tag}/{k}", got[lo:hi], g32[lo:hi])
+            else:
+                check_second_order(f"{tag}/{k}", got[lo:hi], g32[lo:hi], gg[tag + "_g64"].astype(np.float64)[lo:hi])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_plain_bf16_mode_against_the_autocast_reference(golden, case):
+    """mlp_mode = 'fused_bf16' (BASELINE configs[1]): bf16 operands, fp32 accumulate.  Its tolerance is pinned by the
+    imported reference run under torch.autocast('cpu', dtype=bfloat16) (tests/golden/bf16_pano_*.npz): our deviation from
+    the reference's fp32 outputs may be at most 3x the autocast reference's own deviation (+1e-3 of the scale), and the
+    outputs agree with the autocast reference to 1e-2 of the scale; normal-derived outputs (ill-conditioned already in
+    fp32) on the median only."""
+    import pano_nerf_amd as pn
+    g, s, b, gg = golden("pano_full_" + case), golden("stages_" + case), golden("bf16_pano_" + case), golden("grads_pano_" + case)
+    N = s["t_det"].shape[1] - 1
+    rays, env = to_dev(rays_of(s)), to_dev(env_of(golden))
+    model = make_pano(N)
+    model.mlp_mode = "fused_bf16"
+    with torch.no_grad():
+        outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    names = ("comp_rgb", "distance", "ort_loss", "normal", "albedo", "roughness", "surface_rgb", "diffuse", "shading")
+    for lvl, tup in enumerate(outs):
+        for nme, v in zip(names, tup):
+            key = f"val/l{lvl}/{nme}"
+            if v is None:
+                continue
+            got, ref32, ref16 = v.detach().cpu().numpy(), g[key], b[key]
+            scale = max(float(np.abs(ref32).max()), 1e-30)
+            if nme in ("normal", "surface_rgb", "diffuse", "shading"):
+                ours_m = float(np.median(np.abs(got - ref32))) / scale
+                theirs_m = float(np.median(np.abs(ref16 - ref32))) / scale
+                assert ours_m <= 2 * theirs_m + 1e-2, (key, "median", ours_m, theirs_m)
+                continue
+            ours, theirs = float(np.abs(got - ref32).max()) / scale, float(np.abs(ref16 - ref32).max()) / scale
+            assert ours <= 3 * theirs + 1e-3, (key, ours, theirs)
+            assert float(np.abs(got - ref16).max()) / scale <= 1e-2, (key, "vs autocast reference")
+    model.noise_override = dict(t_rand=torch.from_numpy(g["train_t_rand"]), u_rand=torch.from_numpy(g["train_u_rand"]),
+                                env_rand=torch.from_numpy(g["train_env_rand"]))
+    outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    loss, _ = pn.pano_loss(outs, rays.lossmult, torch.from_numpy(s["rgbs"]).to(dev()))
+    ref_loss, ref16_loss = float(gg["loss32"]), float(b["train/loss"])
+    assert abs(float(loss) - ref_loss) <= 3 * abs(ref16_loss - ref_loss) + 2e-3 * abs(ref_loss), (float(loss), ref_loss, ref16_loss)
+    loss.backward()
+    got = model.mlp.last_flat_grad.detach().cpu().numpy().astype(np.float64)
+    g32, g16 = gg["g32"].astype(np.float64), b["train/g"].astype(np.float64)
+    cos = lambda a, c: float(np.dot(a, c) / (np.linalg.norm(a) * np.linalg.norm(c)))
+    # a bf16 gradient is a noisy estimate of the fp32 one (the autocast reference: cosine 0.80-0.85); ours must be at
+    # least as well aligned with the fp32 gradient as the autocast reference is, minus a margin of 0.1
+    assert np.isfinite(got).all()
+    assert cos(got, g32) >= cos(g16, g32) - 0.1, (cos(got, g32), cos(g16, g32))
+
+
+# ---------------------------------------------------------------------------- gate-consistent pointwise parity
+def gates_of(ev, fused):
+    """[9, M, 256] boolean ReLU gates of one evaluation, decoded from the bit words the kernels wrote."""
+    M = ev.M
+    words = ev.masks[:, :M].to(torch.int64) & 0xffffffff  # [9, M, 8]
+    f = torch.arange(256, device=words.device)
+    if fused:  # [M][2 halves][4 words]: word t >> 1 of half hh, bit 16 (t & 1) + e (pn_chain.hip)
+        t, col = f >> 5, f & 31
+        hh, e = (col >> 2) & 1, (col & 3) + 4 * (col >> 3)
+        w, bit = hh * 4 + (t >> 1), 16 * (t & 1) + e
+    else:      # word col / 32, bit c * 8 + i for column 32 (col / 32) + 4 i + c (pn_common.h)
+        w, bit = f >> 5, (f & 3) * 8 + ((f & 31) >> 2)
+    return ((words[:, :, w] >> bit) & 1).bool().cpu()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", CASES)
+def test_gate_consistent_gradients_pointwise(golden, case, mode):
+    """The strong form of gradient parity: the oracle is run with the ReLU gate decisions the GPU kernels took (read back
+    from their bit masks), which removes the one ill-conditioned ingredient — and then EVERY entry of EVERY gradient
+    tensor, first- and second-order alike, must agree to 1e-4 of the tensor max (measured: ~1e-5)."""
+    import pano_nerf_amd as pn
+    g, s = golden("pano_full_" + case), golden("stages_" + case)
+    N = s["t_det"].shape[1] - 1
+    rays_c, env_c = rays_of(s), env_of(golden)
+    rays, env = to_dev(rays_c), to_dev(env_c)
+    model = make_pano(N)
+    model.mlp_mode = mode
+    model.mlp.debug_keep = True
+    noise = dict(t_rand=torch.from_numpy(g["train_t_rand"]), u_rand=torch.from_numpy(g["train_u_rand"]),
+                 env_rand=torch.from_numpy(g["train_env_rand"]))
+    model.noise_override = noise
+    outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    pack = model.mlp.debug_pack
+    e0, e1, ee = pack[5], pack[6], pack[7]
+    gates = [gates_of(e, mode != "layerwise") for e in (e0, e1, ee)]
+    rgbs = torch.from_numpy(s["rgbs"])
+    loss, _ = pn.pano_loss(outs, rays.lossmult, rgbs.to(dev()))
+    loss.backward()
+    got = model.mlp.last_flat_grad.detach().cpu().numpy().astype(np.float64)
+    p = {k: v.clone().requires_grad_(True) for k, v in orc.init_params(4, 5).items()}
+    with orc.forced_gates([gates[0], gates[1], gates[1], gates[2]]):  # level 0, level 1, level-1 normals, env light
+        ref = orc.pano_forward(p, rays_c, orc.Rays(*[x.float() for x in env_c]), num_samples=N, noise=noise)
+        ref_loss = orc.pano_loss(ref, rays_c.lossmult, rgbs)
+        ref_g = torch.autograd.grad(ref_loss, list(p.values()))
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    by_name = {k: x.detach().numpy().astype(np.float64).reshape(-1) for k, x in zip(p.keys(), ref_g)}
+    worst = 0.0
+    for k, lo, hi in tensors(5):
+        r = by_name[k]
+        e = float(np.abs(got[lo:hi] - r).max()) / max(float(np.abs(r).max()), 1e-30)
+        worst = max(worst, e)
+        assert e <= 1e-4, (k, e)
+    print(f"gate-consistent gradients {case} {mode}: worst tensor max-error {worst:.2e}")
