@@ -109,9 +109,6 @@ def main():
     ap.add_argument("--mlp-mode", choices=("fused", "fused_bf16", "layerwise"), default=os.environ.get("PN_MLP_MODE", "fused"),
                     help="fused: on-chip MLP chains, exact 3-term bf16 split (fp32 accuracy; default); fused_bf16: the same "
                          "kernels with plain bf16 operands (BASELINE configs[1]); layerwise: one GEMM launch per layer")
-    ap.add_argument("--gemm-mode", choices=("fp32", "split"), default=None,
-                    help="fp32: exact fp32 MFMA (default); split: fp32-accurate 3-term bf16 split on the bf16 matrix cores "
-                         "(default follows PN_GEMM_MODE)")
     ap.add_argument("--streams", default="auto",
                     help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 2 with <= 2048 "
                          "rays per GPU (+4 %% at 512..2048 rays: the chains fill each other's bubbles), else 1 (at 4096 rays "
@@ -144,10 +141,8 @@ def main():
     import pano_nerf_amd as pn
     from pano_nerf_amd import _lib
     from pano_nerf_amd.dist import shard_bounds
-    split = (args.gemm_mode == "split") if args.gemm_mode else os.environ.get("PN_GEMM_MODE", "0")[:1] == "1"
-    _lib.load().pn_set_gemm_mode(1 if split else 0)
-    # price the NT GEMMs against the matrix-core rate of the instruction they use: fp32 MFMA, or bf16 MFMA / 6 products
-    peak_nt = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
+    split = False  # (the layer-wise split GEMM mode of round 1 is gone: the fused chains supersede it)
+    peak_nt = PEAK_F32_MFMA_TFLOPS
     fused = args.mlp_mode != "layerwise"
     # fused chains: v_mfma_f32_32x32x16_bf16, six products per fp32-equivalent product (split) or one (plain bf16)
     peak_chain = PEAK_BF16_MFMA_TFLOPS / 6.0 if args.mlp_mode == "fused" else PEAK_BF16_MFMA_TFLOPS

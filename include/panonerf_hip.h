@@ -11,13 +11,12 @@
  *   - every pointer is a DEVICE pointer to fp32, row-major, contiguous, unless the
  *     parameter name ends in _host; the caller owns all device memory and the library
  *     allocates none;
- *   - process model: ONE device and ONE host thread per process (how the reference runs
- *     under DDP).  The library keeps three small pieces of process-wide host state, none
- *     of which is a result: the GEMM mode (pn_set_gemm_mode), a pool of hipEvent_t used to
- *     fork / join the optional side stream and by pn_prof_*, and the address ranges of the
- *     two weight blocks whose bf16 planes pn_pack_weights prepared (so that the split GEMM
- *     mode can find the planes of a weight pointer).  Calls are not re-entrant across host
- *     threads;
+ *   - process model: one host thread per device (how the reference runs under DDP).  No entry
+ *     point keeps results or configuration between calls: every operand, workspace and packed
+ *     weight block is passed in.  The only process-wide host state is bookkeeping that never
+ *     reaches a result: the pool of hipEvent_t used to fork / join the optional side stream and
+ *     by the opt-in launch timing (pn_prof_*), the cached CU count of the device, and one flag
+ *     per kernel recording that its dynamic-LDS attribute has been set;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the
  *     call returns without synchronising (graph-capturable);
  *   - return value: 0 on success, negative PN_ERR_* otherwise (the Python shim
@@ -296,16 +295,11 @@ int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* 
                int accumulate, float* work, void* stream);
 
 /* ---- launch timing (bench.py roofline leg; off by default) ------------------------------------
- * pn_prof_enable(on): bit 0 switches the timing on or off; while on, every GEMM launch is bracketed by HIP
- * events on its own stream.  Bits 8 and up are ABLATION switches for the tools/ micro-benchmarks only (skip
- * the stores / loads / MFMAs of a GEMM, force a kernel variant); they change results and are never set by
- * the Python module, the tests or bench.py.  pn_prof_read waits for the recorded events and returns, for
- * kernel class cls (0 = k_gemm_nt, 1 = k_gemm_tn), the summed duration in ms, the launch count and the
- * summed algorithmic FLOPs (2*M*N*K, unpadded). */
-/* GEMM arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp32-accurate 3-term bf16 split on
- * v_mfma_f32_32x32x16_bf16 (six partial products per product, fp32 accumulate).  Default 0 unless the environment
- * variable PN_GEMM_MODE=1 is set before the first GEMM. */
-int pn_set_gemm_mode(int mode);
+ * pn_prof_enable(on): bit 0 switches the timing on or off; while on, every GEMM / chain launch is bracketed by HIP
+ * events on its own stream (the other bits are ignored: the ablation switches of the tools/ micro-benchmarks exist only
+ * in -DPN_ABLATE builds).  pn_prof_read waits for the recorded events and returns, for kernel class cls (0 k_gemm_nt,
+ * 1 k_gemm_tn, 2 k_chain_fwd, 3 k_chain_dgrad, 4 k_chain_tangent, 5 k_chain_bwd, 6 k_chain_wgrad), the summed duration in
+ * ms, the launch count and the summed algorithmic FLOPs (2*M*N*K, unpadded). */
 /* diagnostic: `blocks` workgroups x 4 waves each issue 4*iters back-to-back fp32 MFMAs (no memory traffic) */
 int pn_mfma_probe(float* out, int blocks, int iters, void* stream);
 int pn_prof_enable(int on);

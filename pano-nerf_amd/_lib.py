@@ -46,7 +46,6 @@ SIGNATURES = {
     "pn_gemm_nt": ("i", "liipipipippiip"),
     "pn_gemm_tn_work_floats": ("l", "lii"),
     "pn_gemm_tn": ("i", "liipipipiipp"),
-    "pn_set_gemm_mode": ("i", "i"),
     "pn_chain_pack_bytes": ("l", "i"),
     "pn_chain_pack": ("i", "piipp"),
     "pn_chain_acts_floats": ("l", "l"),

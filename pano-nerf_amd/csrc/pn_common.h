@@ -73,9 +73,6 @@ struct PnProfScope {
     ~PnProfScope();
 };
 
-// bf16 split planes of the weight blocks (pn_gemm.hip keeps the registry; pn_mlp.hip fills the planes)
-void pn_register_planes(int which, const float* fbase, int64_t nfloats, const unsigned short* planes);
-
 // ---- encodings (pn_render.hip) ---------------------------------------------------------
 int pn_launch_ipe_backward(int64_t M, const float* mean, const float* cov, const float* d_enc, float* d_mean,
                            hipStream_t s);

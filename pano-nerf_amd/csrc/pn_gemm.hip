@@ -27,7 +27,16 @@ struct ProfRec {
     double flops;
 };
 static bool g_prof_on = false;
-static int g_dbg = 0;  // ablation switches (tools/bench_gemm.py): pn_prof_enable(on | dbg << 8)
+// Ablation switches of the tools/ micro-benchmarks (skip the stores / loads of a GEMM, force a kernel variant) exist only
+// in -DPN_ABLATE builds (PN_EXTRA=-DPN_ABLATE csrc/build.sh): pn_prof_enable(on | dbg << 8).  The shipped library has none.
+#ifdef PN_ABLATE
+static int g_dbg = 0;
+#define PN_DBG g_dbg
+#define PN_ABL(x) (x)
+#else
+#define PN_DBG 0
+#define PN_ABL(x) 0
+#endif
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_free_events;
 #define PN_PROF_CLASSES 8
@@ -80,7 +89,9 @@ static void prof_drain() {
 extern "C" int pn_prof_enable(int on) {
     prof_drain();
     g_prof_on = (on & 1) != 0;
+#ifdef PN_ABLATE
     g_dbg = on >> 8;
+#endif
     for (int i = 0; i < PN_PROF_CLASSES; ++i) {
         g_prof_ms[i] = 0;
         g_prof_flops[i] = 0;
@@ -212,7 +223,7 @@ __device__ __forceinline__ void nt_epi_slab(const PnGemmNt& g, const float* Ls, 
             if (ok && (lane & 7) == 0) *mp = word;
         }
         if (ok) {
-            if (!(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(cp) = v;
+            if (!PN_ABL(flags & 0x100) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(cp) = v;
             if (flags & PN_EPI_COLSUM) csum += v;
         }
         row += 4;
@@ -259,7 +270,7 @@ __device__ __forceinline__ void nt_epilogue_t(const PnGemmNt& g, f32x16 (&acc)[2
     // wave-uniform: this wave's 64 x 64 block lies inside the matrix -> no bounds tests in the slab steps
     const bool interior = (m0 + wm * 64 + 64 <= g.M) && (n0 + wn * 64 + 64 <= g.N);
     const int known = PN_EPI_BIAS | PN_EPI_ROWBIAS | PN_EPI_ADDC | PN_EPI_RELU | PN_EPI_GATE | PN_EPI_GATEBITS | PN_EPI_MASKOUT |
-                      PN_EPI_COLSUM | 0x100;
+                      PN_EPI_COLSUM | PN_ABL(0x100);
     const int fsel = flags & known;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256, PN_NT_OCC) void k_gemm_nt(PnGemmNt g, int tile
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     auto issue_load = [&](int cidx, NtRegs& r) {
-        if (cidx < nchunks && !(g.flags & 0x200)) {
+        if (cidx < nchunks && !PN_ABL(g.flags & 0x200)) {
             const bool s1 = cidx >= nc0;
             nt_load(s1 ? A1 : A0, s1 ? lda1 : lda0, s1 ? B1 : B0, s1 ? ldb1 : ldb0, s1 ? K1 : K0, Mrows, Ncols,
                     (s1 ? cidx - nc0 : cidx) * BK, m0, n0, tid, r);
@@ -497,325 +508,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm_nt_dma(PnGemmNt g, int tiles_n,
 #endif
 }
 
-// ---- NT on the bf16 matrix cores with fp32 accuracy: 3-term split ------------------------------------------
-// Every fp32 operand element x is split exactly as x = h + m + l with h = bf16(x), m = bf16(x - h),
-// l = bf16(x - h - m) (3 x 8 = 24 mantissa bits).  The product a*b is accumulated in fp32 from the six partial
-// products of weight >= 2^-16 (hh, hm, mh, mm, hl, lh; the dropped ml, lm, ll are <= 2^-24 relative, the size of an
-// fp32 rounding), each a v_mfma_f32_32x32x16_bf16 — 16x the fp32-MFMA rate, so 6 of them cost 0.375 of one fp32
-// MFMA of the same tile.  Interfaces stay fp32: the split happens in the staging path (global fp32 -> registers ->
-// three bf16 planes in LDS); accumulators, epilogue and outputs are exactly those of the fp32 kernels.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#define SK 16  // K-chunk of the split kernels
-
-__device__ __forceinline__ void split4(const f32x4& x, bf16x4& h, bf16x4& m, bf16x4& l) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const __bf16 hh = (__bf16)x[c];
-        const float r1 = x[c] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        const float r2 = r1 - (float)mm;
-        h[c] = hh;
-        m[c] = mm;
-        l[c] = (__bf16)r2;
-    }
-}
-
-// plane image: [3 planes][128 rows][16 k] bf16 (32-B rows); the two 16-B pieces of a row are swapped on rows with
-// bit 3 set, which makes both the 8-B staging writes and the 16-B fragment reads bank-conflict free
-__device__ __forceinline__ int s3_off(int plane, int row, int piece) {
-    return ((plane * 128 + row) * SK) + ((piece ^ ((row >> 3) & 1)) << 3);
-}
-
-struct S3Regs {
-    f32x4 a[2], b[2];
-};
-
-__global__ __launch_bounds__(256, 3) void k_gemm_nt_s3(PnGemmNt g, int tiles_n, int ntiles) {
-    __shared__ __attribute__((aligned(16))) unsigned short smem_s[2 * 2 * 3 * 128 * SK];  // 2 buffers x (A,B) x 3 planes: 48 KB
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int nc0 = g.seg[0].K / SK;
-    const int nc1 = (g.nseg > 1) ? g.seg[1].K / SK : 0;
-    const int nchunks = nc0 + nc1;
-    const float* const A0 = g.seg[0].A;
-    const float* const B0 = g.seg[0].B;
-    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb;
-    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
-    const float* const B1 = g.nseg > 1 ? g.seg[1].B : B0;
-    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
-    const int t = xcd_remap(blockIdx.x, ntiles);
-    const int64_t m0 = (int64_t)(t / tiles_n) * BM;
-    const int n0 = (t % tiles_n) * BN;
-
-    // staging: thread -> (row rr and rr + 64, k-quad q)
-    const int sq = tid & 3, srow = tid >> 2;
-    int64_t ar0 = m0 + srow, ar1 = ar0 + 64;
-    ar0 = ar0 < g.M ? ar0 : g.M - 1;
-    ar1 = ar1 < g.M ? ar1 : g.M - 1;
-    int br0 = n0 + srow, br1 = br0 + 64;
-    br0 = br0 < g.N ? br0 : g.N - 1;
-    br1 = br1 < g.N ? br1 : g.N - 1;
-    auto load = [&](int c, S3Regs& r) {
-        const bool s1 = c >= nc0;
-        const float* A = s1 ? A1 : A0;
-        const float* B = s1 ? B1 : B0;
-        const int lda = s1 ? lda1 : lda0, ldb = s1 ? ldb1 : ldb0;
-        const int k = (s1 ? c - nc0 : c) * SK + sq * 4;
-        r.a[0] = *reinterpret_cast<const f32x4*>(A + ar0 * lda + k);
-        r.a[1] = *reinterpret_cast<const f32x4*>(A + ar1 * lda + k);
-        r.b[0] = *reinterpret_cast<const f32x4*>(B + (int64_t)br0 * ldb + k);
-        r.b[1] = *reinterpret_cast<const f32x4*>(B + (int64_t)br1 * ldb + k);
-    };
-    auto store = [&](int buf, const S3Regs& r) {
-        unsigned short* as = smem_s + buf * (6 * 128 * SK);
-        unsigned short* bs = as + 3 * 128 * SK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = srow + 64 * i;
-            const int o = ((sq >> 1) ^ ((row >> 3) & 1)) * 8 + (sq & 1) * 4;
-            bf16x4 h, m, l;
-            split4(r.a[i], h, m, l);
-            *reinterpret_cast<bf16x4*>(as + (0 * 128 + row) * SK + o) = h;
-            *reinterpret_cast<bf16x4*>(as + (1 * 128 + row) * SK + o) = m;
-            *reinterpret_cast<bf16x4*>(as + (2 * 128 + row) * SK + o) = l;
-            split4(r.b[i], h, m, l);
-            *reinterpret_cast<bf16x4*>(bs + (0 * 128 + row) * SK + o) = h;
-            *reinterpret_cast<bf16x4*>(bs + (1 * 128 + row) * SK + o) = m;
-            *reinterpret_cast<bf16x4*>(bs + (2 * 128 + row) * SK + o) = l;
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    S3Regs regs;
-    load(0, regs);
-    store(0, regs);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load(c + 1, regs);
-        const unsigned short* as = smem_s + buf * (6 * 128 * SK);
-        const unsigned short* bs = as + 3 * 128 * SK;
-        bf16x8 a[2][3], b[2][3];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[tt][p] = *reinterpret_cast<const bf16x8*>(as + s3_off(p, wm * 64 + tt * 32 + fr, fh));
-                b[tt][p] = *reinterpret_cast<const bf16x8*>(bs + s3_off(p, wn * 64 + tt * 32 + fr, fh));
-            }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                f32x16 v = acc[tm][tn];  // small terms first
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], v, 0, 0, 0);
-                acc[tm][tn] = v;
-            }
-        if (c + 1 < nchunks) store(buf ^ 1, regs);
-        __syncthreads();
-    }
-    nt_epilogue(g, acc, reinterpret_cast<float*>(smem_s), m0, n0, lane, wid, wm, wn);
-}
-
-// ---- pre-split weight planes (N = 256 layers) ------------------------------------------------------------------
-// The B operand (weights) arrives as bf16 planes prepared once per optimizer step by pn_pack_weights and is moved
-// global -> LDS by DMA with the swizzle on the source address.
-struct PlaneRef {
-    const unsigned short* base;  // plane 0 of the element the fp32 pointer addresses; plane p at + p * stride
-    int64_t stride;
-};
-static const float* g_pl_f[2] = {nullptr, nullptr};       // fp32 blocks the planes mirror (params, wpack)
-static const unsigned short* g_pl_p[2] = {nullptr, nullptr};
-static int64_t g_pl_n[2] = {0, 0};
-void pn_register_planes(int which, const float* fbase, int64_t nfloats, const unsigned short* planes) {
-    g_pl_f[which] = fbase;
-    g_pl_n[which] = nfloats;
-    g_pl_p[which] = planes;
-}
-static bool lookup_planes(const float* B, PlaneRef& r) {
-    for (int i = 0; i < 2; ++i)
-        if (g_pl_f[i] && B >= g_pl_f[i] && B < g_pl_f[i] + g_pl_n[i]) {
-            r.base = g_pl_p[i] + (B - g_pl_f[i]);
-            r.stride = g_pl_n[i];
-            return true;
-        }
-    return false;
-}
-struct S3wArgs {
-    PlaneRef bp[2];
-};
-
-__device__ __forceinline__ int s3w_off(int plane, int rows, int row, int piece) {
-    return ((plane * rows + row) * SK) + ((piece ^ ((row >> 3) & 1)) << 3);
-}
-
-// ---- split kernel, all-DMA staging: 256 x 256 tile, fp32 A by LDS-DMA, three chunks in the ring ----------------
-// At bf16 speed a 16-wide chunk of this tile is ~1.3 us of MFMA work, shorter than the loaded HBM latency, and
-// hipcc drains vmcnt to 0 at the first use of an ordinary global load while an LDS-DMA is in flight — so register
-// staging of A (an earlier kernel, removed) leaves the matrix cores waiting on every chunk (PMC: MFMA busy 40 %, waves parked
-// 34 %).  Here BOTH operands arrive by LDS-DMA: A as raw fp32 rows (the image of k_gemm_nt_dma, swizzle on the source
-// address), B as the pre-split bf16 planes; a ring of three buffers keeps two chunks in flight behind the one being
-// multiplied, retired by a COUNTED vmcnt and a raw s_barrier (no fence, hence no vmcnt(0)).  Each wave splits the A
-// fragments it needs in registers (16 values per lane and chunk), so there are no A planes in LDS at all.
-#define S3F_NB 3
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
-    bf16x4 h0, m0, l0, h1, m1, l1;
-    split4(x0, h0, m0, l0);
-    split4(x1, h1, m1, l1);
-    h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    m = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-    l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-__global__ __launch_bounds__(512, 2) void k_gemm_nt_s3f(PnGemmNt g, S3wArgs w, int ntiles) {
-    // per ring slot: raw A [256 rows][16 floats] (16 KB) then B planes 3 x [256][16] bf16 (24 KB)
-    constexpr int A_FLOATS = 256 * SK, B_SHORTS = 3 * 256 * SK;
-    constexpr int SLOT_BYTES = A_FLOATS * 4 + B_SHORTS * 2;  // 40 960
-    __shared__ __attribute__((aligned(16))) unsigned char smem_b[S3F_NB * SLOT_BYTES];  // 120 KB
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int nc0 = g.seg[0].K / SK;
-    const int nc1 = (g.nseg > 1) ? g.seg[1].K / SK : 0;
-    const int nchunks = nc0 + nc1;
-    const float* const A0 = g.seg[0].A;
-    const int lda0 = g.seg[0].lda, ldb0 = g.seg[0].ldb;
-    const float* const A1 = g.nseg > 1 ? g.seg[1].A : A0;
-    const int lda1 = g.nseg > 1 ? g.seg[1].lda : lda0, ldb1 = g.nseg > 1 ? g.seg[1].ldb : ldb0;
-    const unsigned short* const P0 = w.bp[0].base;
-    const unsigned short* const P1 = g.nseg > 1 ? w.bp[1].base : P0;
-    const int64_t ps0 = w.bp[0].stride, ps1 = g.nseg > 1 ? w.bp[1].stride : ps0;
-    const int64_t m0 = (int64_t)blockIdx.x * 256;  // one tile column: N == 256
-
-    // A DMA: 16 pieces of 16 rows per chunk, wave w moves pieces w and w + 8; lane -> (row = lane >> 2, slot = lane & 3);
-    // slot s of local row r holds source k-piece s ^ ((r >> 2) & 3)
-    const int arow_l = lane >> 2;
-    const int aq = (lane & 3) ^ ((arow_l >> 2) & 3);
-    int64_t arow0 = m0 + wid * 16 + arow_l, arow1 = arow0 + 128;
-    arow0 = arow0 < g.M ? arow0 : g.M - 1;
-    arow1 = arow1 < g.M ? arow1 : g.M - 1;
-    // B DMA: 3 planes x 8 pieces of 32 rows; wave w moves piece w of every plane
-    const int dr = lane >> 1;
-    const int dsp = (lane & 1) ^ ((dr >> 3) & 1);
-    auto stage = [&](int c, int slot) {
-        const bool s1 = c >= nc0;
-        const float* A = s1 ? A1 : A0;
-        const int lda = s1 ? lda1 : lda0;
-        const unsigned short* P = s1 ? P1 : P0;
-        const int64_t ps = s1 ? ps1 : ps0;
-        const int ldb = s1 ? ldb1 : ldb0;
-        const int kc = (s1 ? c - nc0 : c) * SK;
-        unsigned char* base = smem_b + slot * SLOT_BYTES;
-        float* as = reinterpret_cast<float*>(base);
-        unsigned short* bs = reinterpret_cast<unsigned short*>(base + A_FLOATS * 4);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + arow0 * lda + kc + aq * 4), (lds_ptr_t)(as + (wid * 16) * SK), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + arow1 * lda + kc + aq * 4), (lds_ptr_t)(as + (wid * 16 + 128) * SK), 16, 0, 0);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(P + p * ps + (int64_t)(wid * 32 + dr) * ldb + kc + dsp * 8),
-                                             (lds_ptr_t)(bs + (p * 256 + wid * 32) * SK), 16, 0, 0);
-    };  // 5 DMA instructions per wave and chunk
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const int asw = (fr >> 2) & 3;  // rows wm*64 + tt*32 + fr: the multiples of 32 do not change (r >> 2) & 3
-    stage(0, 0);
-    if (nchunks > 1) {
-        stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    int slot = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more2 = c + 2 < nchunks;
-        int slot2 = slot + 2;
-        slot2 = slot2 >= S3F_NB ? slot2 - S3F_NB : slot2;
-        if (more2 && !(g.flags & 0x800)) stage(c + 2, slot2);  // that slot held chunk c - 1 (0x800: ablation, no DMA)
-        const unsigned char* base = smem_b + slot * SLOT_BYTES;
-        const float* as = reinterpret_cast<const float*>(base);
-        const unsigned short* bs = reinterpret_cast<const unsigned short*>(base + A_FLOATS * 4);
-        bf16x8 a[2][3];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const float* row = as + (wm * 64 + tt * 32 + fr) * SK;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + (((2 * fh) ^ asw) << 2));
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + (((2 * fh + 1) ^ asw) << 2));
-            if (g.flags & 0x10000) {  // ablation: no split arithmetic (three copies of the raw bits)
-                bf16x8 t;
-                __builtin_memcpy(&t, &x0, 16);
-                a[tt][0] = a[tt][1] = a[tt][2] = t;
-                a[tt][1][0] = (__bf16)x1[0];
-            } else {
-                split8(x0, x1, a[tt][0], a[tt][1], a[tt][2]);
-            }
-        }
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            bf16x8 b[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[p] = *reinterpret_cast<const bf16x8*>(bs + s3w_off(p, 256, wn * 128 + tn * 32 + fr, fh));
-            if (g.flags & 0x8000) {  // ablation: no MFMAs (keep the fragments alive)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) acc[tm][tn][0] += (float)a[tm][0][0] + (float)a[tm][1][1] + (float)a[tm][2][2] + (float)b[0][0] + (float)b[1][1] + (float)b[2][2];
-                continue;
-            }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                f32x16 v = acc[tm][tn];  // small terms first
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[0], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[2], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[1], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[0], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[1], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[0], v, 0, 0, 0);
-                acc[tm][tn] = v;
-            }
-        }
-        // chunk c + 1 (issued one iteration ago) must have landed; chunk c + 2 (5 DMAs, just issued) stays in flight
-        if (more2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        slot = slot + 1 >= S3F_NB ? 0 : slot + 1;
-    }
-    nt_epilogue_t<4, 0>(g, acc, reinterpret_cast<float*>(smem_b), m0, wn * 128, lane, wid, wm, 0);
-    nt_epilogue_t<4, 2>(g, acc, reinterpret_cast<float*>(smem_b), m0, wn * 128 + 64, lane, wid, wm, 0);
-}
-
-static int g_gemm_mode = -1;  // 0 = exact fp32 MFMA, 1 = 3-term bf16 split; -1 = read PN_GEMM_MODE on first use
-static int gemm_mode() {
-    if (g_gemm_mode < 0) {
-        const char* e = getenv("PN_GEMM_MODE");
-        g_gemm_mode = (e && e[0] == '1') ? 1 : 0;
-    }
-    return g_gemm_mode;
-}
-extern "C" int pn_set_gemm_mode(int mode) {
-    if (mode != 0 && mode != 1) return PN_ERR_UNSUPPORTED;
-    g_gemm_mode = mode;
-    return PN_OK;
-}
-
 int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.nseg < 1 || g.nseg > 2) return PN_ERR_BAD_SHAPE;
     for (int i = 0; i < g.nseg; ++i) {
@@ -841,24 +533,10 @@ int pn_launch_gemm_nt(const PnGemmNt& g, hipStream_t s) {
     double ksum = 0;
     for (int i = 0; i < g.nseg; ++i) ksum += g.seg[i].K;
     ProfScope prof(0, 2.0 * (double)g.M * g.N * ksum, s);
-    PnGemmNt gg = g;
-    bool dma = !(g_dbg & 64) && !(g.flags & 0x200);
+    bool dma = !(PN_DBG & 64) && !PN_ABL(g.flags & 0x200);
     for (int i = 0; i < g.nseg; ++i) dma = dma && (g.seg[i].K % DK == 0);
-    bool split = gemm_mode() == 1 && !(g.flags & 0x200);
-    if (g_dbg & 0x19c00) gg.flags |= (g_dbg & 0x19c00);  // split-kernel ablations
-    for (int i = 0; i < g.nseg; ++i) split = split && (g.seg[i].K % SK == 0);
-    S3wArgs wa;
-    bool wide = split && g.N == 256 && !(g_dbg & 256);
-    for (int i = 0; i < g.nseg && wide; ++i)
-        wide = lookup_planes(g.seg[i].B, wa.bp[i]) && (g.seg[i].ldb % 8 == 0) &&
-               ((reinterpret_cast<uintptr_t>(wa.bp[i].base) & 15) == 0) && (wa.bp[i].stride % 8 == 0);
-    if (wide) {
-        const unsigned tiles256 = (unsigned)((g.M + 255) / 256);
-        hipLaunchKernelGGL(k_gemm_nt_s3f, dim3(tiles256), dim3(512), 0, s, gg, wa, (int)tiles256);
-    }
-    else if (split) hipLaunchKernelGGL(k_gemm_nt_s3, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
-    else if (dma) hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
-    else hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, gg, tiles_n, (int)nwg);
+    if (dma) hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)nwg), dim3(256), 0, s, g, tiles_n, (int)nwg);
+    else hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)nwg), dim3(256), 0, s, g, tiles_n, (int)nwg);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
@@ -1274,7 +952,7 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
     g.N1 = N1;
     g.N2 = N2;
     g.chunks_total = chunks;
-    const bool wide = (N1 % 128 == 0) && (N2 % 256 == 0) && !(g_dbg & 128);
+    const bool wide = (N1 % 128 == 0) && (N2 % 256 == 0) && !(PN_DBG & 128);
     int nsplit = tn_splits(Mtotal, N1, N2);
     if (work_avail >= 0 && (int64_t)nsplit * N1 * N2 > work_avail) return PN_ERR_BAD_SHAPE;  // slab too small
     int64_t per = (g.chunks_total + nsplit - 1) / nsplit;

@@ -83,24 +83,6 @@ __global__ void k_copy_cols(const float* src, int ld, int c0, int rows, int cols
     dst[idx] = (c < cols) ? src[(int64_t)r * ld + c0 + c] : 0.f;
 }
 
-// planes[p * n + i] = p-th bf16 term of the exact 3-term split of src[i]
-__global__ void k_split_planes(const float* src, int64_t n, unsigned short* planes) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = src[i];
-    const __bf16 h = (__bf16)x;
-    const float r1 = x - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const __bf16 l = (__bf16)(r1 - (float)m);
-    unsigned short hb, mb, lb;
-    __builtin_memcpy(&hb, &h, 2);
-    __builtin_memcpy(&mb, &m, 2);
-    __builtin_memcpy(&lb, &l, 2);
-    planes[i] = hb;
-    planes[n + i] = mb;
-    planes[2 * n + i] = lb;
-}
-
 // all weight transposes of one pn_pack_weights call in ONE launch: a workgroup finds its job in a small table
 struct TrJob {
     const float* src;
@@ -524,12 +506,9 @@ int64_t pn_param_layout(int nc, int64_t* off) {
     return L.total;
 }
 
-// workspace = [packed fp32 weights | bf16 planes of the parameter block | bf16 planes of the packed weights]
-static int64_t planes_floats(int64_t n) { return (3 * n * 2 + 3) / 4 + 4; }  // 3 planes of n bf16, in floats, 16-B slack
 int64_t pn_wpack_floats(int nc) {
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    const int64_t np = pn_layout(nc).total, nw = pn_pack_layout().total;
-    return nw + planes_floats(np) + planes_floats(nw);
+    return pn_pack_layout().total;
 }
 
 int pn_pack_weights(const float* params, int nc, float* wpack, void* stream) {
@@ -555,13 +534,6 @@ int pn_pack_weights(const float* params, int nc, float* wpack, void* stream) {
     hipLaunchKernelGGL(k_copy_cols, dim3(nblk(PN_WIDTH_COND * 32, 256)), dim3(256), 0, s, params + L.wv, ldv, PN_WIDTH,
                        PN_WIDTH_COND, PN_VIEW_DIM, 32, wpack + P.wvv);
     PN_CHECK_LAUNCH();
-    // bf16 split planes of both weight blocks (B operands of the split GEMM kernels, fetched by LDS-DMA)
-    unsigned short* plp = reinterpret_cast<unsigned short*>(wpack + P.total);
-    unsigned short* plw = reinterpret_cast<unsigned short*>(wpack + P.total + planes_floats(L.total));
-    hipLaunchKernelGGL(k_split_planes, dim3(nblk(L.total, 256)), dim3(256), 0, s, params, L.total, plp);
-    PN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_split_planes, dim3(nblk(P.total, 256)), dim3(256), 0, s, wpack, P.total, plw);
-    PN_CHECK_LAUNCH();
     return PN_OK;
 }
 
@@ -578,13 +550,6 @@ int pn_mlp_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, const
     PnPack P = pn_pack_layout();
     const int64_t Mp = pn_pad(M);
     auto act = [&](int i) { return acts + (int64_t)i * Mp * PN_WIDTH; };
-    {
-        const PnLayout L_ = pn_layout(nc);
-        const PnPack P_ = pn_pack_layout();
-        pn_register_planes(0, params, L_.total, reinterpret_cast<const unsigned short*>(wpack + P_.total));
-        pn_register_planes(1, wpack, P_.total,
-                           reinterpret_cast<const unsigned short*>(wpack + P_.total + planes_floats(L_.total)));
-    }
 
     RUN(pn_ipe_encode(M, mean, cov, enc, stream));
     RUN(pn_pos_enc_view(view_rows, viewdirs, viewenc, stream));
@@ -647,13 +612,6 @@ int pn_density_grad(int64_t M, int nc, float density_bias, const float* params, 
     const int64_t Mp = pn_pad(M);
     auto act = [&](int i) { return acts + (int64_t)i * Mp * PN_WIDTH; };
     auto rs = [&](int i) { return rsweep + (int64_t)i * Mp * PN_WIDTH; };
-    {
-        const PnLayout L_ = pn_layout(nc);
-        const PnPack P_ = pn_pack_layout();
-        pn_register_planes(0, params, L_.total, reinterpret_cast<const unsigned short*>(wpack + P_.total));
-        pn_register_planes(1, wpack, P_.total,
-                           reinterpret_cast<const unsigned short*>(wpack + P_.total + planes_floats(L_.total)));
-    }
     hipLaunchKernelGGL(k_dgrad_seed, dim3(nblk(M * (PN_WIDTH / 4), 256)), dim3(256), 0, s, M, nc, density_bias,
                        raw_density, params + L.wd, masks + (int64_t)7 * Mp * PN_MASK_WORDS, rs(7));
     PN_CHECK_LAUNCH();
@@ -864,13 +822,6 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, floa
     };
     const bool inline_tangent = v_gradmean && !defer_wgrad && n_deferred == 0;  // stand-alone call: as before
 
-    {
-        const PnLayout L_ = pn_layout(nc);
-        const PnPack P_ = pn_pack_layout();
-        pn_register_planes(0, params, L_.total, reinterpret_cast<const unsigned short*>(wpack + P_.total));
-        pn_register_planes(1, wpack, P_.total,
-                           reinterpret_cast<const unsigned short*>(wpack + P_.total + planes_floats(L_.total)));
-    }
     RUN(hand_off());  // inputs produced earlier on the main stream
     // colour-head weight gradient only needs inputs: start the side stream with it
     RUN((head_bwd_weight<2, 3>(M, d_raw_rgb, 3, nullptr, act(9), PN_WIDTH, grads + L.wc, grads + L.bc, partial, ws)));
@@ -1002,7 +953,11 @@ int pn_gemm_nt(int64_t M, int N, int K, const float* A, int lda, const float* Bt
     g.bias = bias;
     g.gate = gate;
     g.ldg = ldg;
+    #ifdef PN_ABLATE
     g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE | 0x300);  // 0x100/0x200: ablation (tools/bench_gemm.py)
+#else
+    g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE);
+#endif
     return pn_launch_gemm_nt(g, ST(stream));
 }
 

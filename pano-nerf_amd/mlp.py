@@ -59,7 +59,8 @@ class RadianceMLP(torch.nn.Module):
         self.flat = None
         self._version_packed = None
         self._wpack = None
-        self._chain = {}  # planes -> (version, packed chains of the fused kernels)
+        self._chain = {}  # planes -> packed chains of the fused kernels (buffer reused, contents rebuilt per call)
+        self._frozen = False  # concurrent_step: packs built once before the sub-batch streams fork
         self.last_flat_grad = None
         self._flatten()
 
@@ -99,36 +100,38 @@ class RadianceMLP(torch.nn.Module):
             self._flatten()
         return self.flat
 
-    def packed(self, stream):
-        """Transposed / split weight copies used by the backward-direction GEMMs; rebuilt when any
-        parameter changed (tensor version counters) — i.e. once per optimizer step."""
-        flat = self.flat_params()
-        version = tuple(p._version for _, p in self.named_in_order()) + (flat._version, flat.data_ptr())
-        if self._wpack is None or self._wpack.device != flat.device or version != self._version_packed:
-            n = _lib.load().pn_wpack_floats(self.num_density_channels)
-            if self._wpack is None or self._wpack.device != flat.device:
-                self._wpack = torch.empty(n, dtype=torch.float32, device=flat.device)
-            _lib.call("pn_pack_weights", flat.data_ptr(), self.num_density_channels, self._wpack.data_ptr(), stream)
-            self._version_packed = version
-        return self._wpack
-
     def _version(self):
+        """Autograd version counters of the 24 parameters and of the flat block (in-place writes that go through torch
+        bump them; `p.data.copy_`, raw device writes and collectives do not — hence the packs below are rebuilt on every
+        call rather than cached on this key)."""
         flat = self.flat_params()
         return tuple(p._version for _, p in self.named_in_order()) + (flat._version, flat.data_ptr())
 
+    def packed(self, stream):
+        """Transposed / split weight copies used by the layer-wise GEMM path (pn_pack_weights).  Rebuilt on EVERY call:
+        a write that bypasses the version counters (p.data.copy_, an EMA update, a custom loader, a collective into
+        `flat`) must never leave the backward-direction GEMMs on stale copies, and the pack is one ~2.4 MB pass."""
+        flat = self.flat_params()
+        if self._wpack is None or self._wpack.device != flat.device:
+            n = _lib.load().pn_wpack_floats(self.num_density_channels)
+            self._wpack = torch.empty(n, dtype=torch.float32, device=flat.device)
+        elif self._frozen:
+            return self._wpack
+        _lib.call("pn_pack_weights", flat.data_ptr(), self.num_density_channels, self._wpack.data_ptr(), stream)
+        return self._wpack
+
     def chain_packed(self, stream, planes):
         """Fragment-ordered bf16 planes of every weight matrix, in both directions, for the fused chain kernels
-        (pn_chain_pack); rebuilt when any parameter changed, like `packed`."""
+        (pn_chain_pack: one launch, ~7 MB written); rebuilt on every call for the same reason as `packed`."""
         flat = self.flat_params()
-        version = self._version()
-        hit = self._chain.get(planes)
-        if hit is None or hit[0] != version or hit[1].device != flat.device:
-            buf = hit[1] if (hit is not None and hit[1].device == flat.device) else torch.empty(
-                int(_lib.load().pn_chain_pack_bytes(planes)), dtype=torch.uint8, device=flat.device)
-            _lib.call("pn_chain_pack", flat.data_ptr(), self.num_density_channels, planes, buf.data_ptr(), stream)
-            self._chain[planes] = (version, buf)
-            hit = self._chain[planes]
-        return hit[1]
+        buf = self._chain.get(planes)
+        if buf is None or buf.device != flat.device:
+            buf = torch.empty(int(_lib.load().pn_chain_pack_bytes(planes)), dtype=torch.uint8, device=flat.device)
+            self._chain[planes] = buf
+        elif self._frozen:
+            return buf
+        _lib.call("pn_chain_pack", flat.data_ptr(), self.num_density_channels, planes, buf.data_ptr(), stream)
+        return buf
 
     def grad_views(self, flat_grad):
         return [flat_grad[self._offsets[k]:self._offsets[k] + p.numel()].view(p.shape) for k, p in self.named_in_order()]
@@ -138,6 +141,5 @@ class RadianceMLP(torch.nn.Module):
 
 
 def mark_dirty(mlp):
-    """Tell the container its flat block was written outside torch (e.g. by pn_adam_step)."""
+    """Kept for callers of round 1 (the packs are rebuilt on every forward now; nothing to invalidate)."""
     mlp._version_packed = None
-    mlp._chain = {}

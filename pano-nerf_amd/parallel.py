@@ -39,16 +39,24 @@ def concurrent_step(model, loss_fn, rays, rgbs, parts=2, **forward_kwargs):
     cur = torch.cuda.current_stream(dev)
     # the transposed / split weight copies are rebuilt after every optimizer step: do it once, BEFORE the fork, so no
     # sub-batch reads them while another one's first forward is still writing them
-    model.mlp.packed(cur.cuda_stream)
+    from .render import _planes_of
+    planes = _planes_of(model.mlp_mode)
+    model.mlp._frozen = False
+    if planes:
+        model.mlp.chain_packed(cur.cuda_stream, planes)
+    else:
+        model.mlp.packed(cur.cuda_stream)
     side = _streams(dev, parts - 1)
     for s in side:
         s.wait_stream(cur)
     grads, losses, first = [], [], None
     model.mlp.defer_param_grads = True  # _RenderFn.backward leaves the flat gradient in mlp.last_flat_grad only
+    model.mlp._frozen = True            # the sub-batches reuse the packs built above
     try:
         return _run_parts(model, loss_fn, rays, rgbs, parts, forward_kwargs, B, cur, side, grads, losses)
     finally:
         model.mlp.defer_param_grads = False
+        model.mlp._frozen = False
 
 
 def _run_parts(model, loss_fn, rays, rgbs, parts, forward_kwargs, B, cur, side, grads, losses):

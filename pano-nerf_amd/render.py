@@ -257,9 +257,15 @@ class _RenderFn(torch.autograd.Function):
                           env_d.data_ptr(), env_omega.data_ptr(), diffuse.data_ptr(), shading.data_ptr(), st)
                 surface = diffuse.clone()
         ctx.cfg, ctx.mlp = cfg, mlp
-        ctx.pack = (o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, albedo, normal, params, wpack)
-        if getattr(mlp, "debug_keep", False):  # diagnostics only (tests/diag/diag_full.py)
-            mlp.debug_pack = ctx.pack
+        # `normal` and `albedo` are OUTPUTS of this Function: they go through save_for_backward (an output kept as a plain
+        # ctx attribute makes an output -> grad_fn -> ctx -> output cycle that only backward() would break; a forward
+        # that is never back-propagated would leak its activation buffers).  The evaluation buffers are not outputs.
+        ctx.has_normal, ctx.has_albedo = normal is not None, albedo is not None
+        ctx.save_for_backward(*[x for x in (normal, albedo) if x is not None])
+        ctx.pack = (o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, params, wpack)
+        ctx.param_version = mlp._version() if keep else None
+        if getattr(mlp, "debug_keep", False):  # diagnostics only (tests/diag/diag_full.py, tests/test_gpu_grads.py)
+            mlp.debug_pack = (o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, albedo, normal, params, wpack)
         outs = (comp0, dist0, comp1, dist1, ort, normal, albedo, surface, diffuse, shading)
         ctx.present = [x is not None for x in outs]
         return tuple(x if x is not None else torch.zeros((), device=dev) for x in outs)
@@ -268,7 +274,15 @@ class _RenderFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_comp0, g_dist0, g_comp1, g_dist1, g_ort, g_normal, g_albedo, g_surface, g_diffuse, g_shading):
         cfg, mlp = ctx.cfg, ctx.mlp
-        o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, albedo, normal, params, wpack = ctx.pack
+        if ctx.pack is None:
+            raise RuntimeError("pano_nerf_amd: backward through the same render twice (its buffers were released)")
+        o, d, vd, env_d, env_omega, e0, e1, ee, w1, env_rgb, params, wpack = ctx.pack
+        saved = list(ctx.saved_tensors)
+        normal = saved.pop(0) if ctx.has_normal else None
+        albedo = saved.pop(0) if ctx.has_albedo else None
+        if ctx.param_version is not None and mlp._version() != ctx.param_version:
+            raise RuntimeError("pano_nerf_amd: the MLP parameters were modified in place between forward and backward "
+                               "(e.g. an optimizer step before backward()); the saved activations belong to the old weights")
         dev = o.device
         B, N, nc = o.shape[0], cfg.num_samples, cfg.nc
         M = B * N

@@ -1,0 +1,153 @@
+"""The fused chain kernels through the C ABI (pn_chain_*), against an fp64 PyTorch evaluation of the same MLP built from
+the oracle's functions: forward activations and raw outputs; then — with the ReLU gates the kernels recorded forced into
+the fp64 model — the density-gradient sweep, the tangent sweep, the data-gradient chain and the T32 weight-gradient GEMMs
+against autograd of   L = <d_rgb, raw_rgb> + <d_den, raw_density> + <v, d sigma / d mean>   (first- and second-order
+terms in one scalar).  Ragged sizes, cycling view rows (the env-light pattern), both density-head widths."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pano_oracle as orc
+from test_gpu_grads import gates_of
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def t32_rows(t, Mp, F):
+    return t.reshape(Mp // 32, F, 32).permute(0, 2, 1).reshape(Mp, F)
+
+
+class Ev:
+    pass
+
+
+class EvalC(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int64)] + [(k, ctypes.c_void_p) for k in
+                ("enc_t", "acts_t", "drgb_t", "dhv_t", "d8_t", "delta_t", "rs_t", "edot_t", "tang_t", "coef_t")]
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("M,rows_per_ray,view_rows,nc", [(2048, 32, 64, 5), (3000, 10, 10, 5), (130 * 7, 7, 130, 1)])
+def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc):
+    from pano_nerf_amd import _lib
+    lib = _lib.load()
+    E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev())
+    Z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev())
+    gen = torch.Generator().manual_seed(M)
+    params = orc.init_params(21, nc)
+    # larger weights than the initialisation: activations spread over several binades
+    params = {k: v * (3.0 if k.endswith("weight") and k.startswith("layers") else 1.0) for k, v in params.items()}
+    import pano_nerf_amd as pn
+    from pano_nerf_amd.mlp import ORDER, param_layout
+    offs, total = param_layout(nc)
+    flat = torch.zeros(total)
+    for k in ORDER:
+        flat[offs[k]:offs[k] + params[k].numel()] = params[k].reshape(-1)
+    flat_d = flat.to(dev())
+    mean = (torch.rand(M, 3, generator=gen) - 0.5) * 8
+    cov = torch.rand(M, 3, generator=gen) * 1e-3
+    vd = torch.nn.functional.normalize(torch.randn(view_rows, 3, generator=gen), dim=-1)
+    d_rgb, d_den, v = torch.randn(M, 3, generator=gen), torch.randn(M, nc, generator=gen), torch.randn(M, 3, generator=gen)
+    Mp = int(lib.pn_pad_rows(M))
+    dbias = -1.0
+    planes = 3
+    pack = torch.empty(int(lib.pn_chain_pack_bytes(planes)), dtype=torch.uint8, device=dev())
+    _lib.call("pn_chain_pack", flat_d.data_ptr(), nc, planes, pack.data_ptr(), st())
+    ev = Ev()
+    ev.M, ev.Mp = M, Mp
+    mean_d, cov_d, vd_d = mean.to(dev()), cov.to(dev()), vd.to(dev())
+    enc_t, acts_t = E(Mp * 96), E(int(lib.pn_chain_acts_floats(M)))
+    ev.masks = torch.zeros(9, Mp, 8, dtype=torch.int32, device=dev())
+    rr, rd = E(M, 3), E(M, nc)
+    _lib.call("pn_chain_forward", M, rows_per_ray, view_rows, nc, planes, pack.data_ptr(), mean_d.data_ptr(), cov_d.data_ptr(),
+              vd_d.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), ev.masks.data_ptr(), rr.data_ptr(), rd.data_ptr(), st())
+    torch.cuda.synchronize()
+
+    # ---- fp64 model (natural gates): forward values
+    p64 = {k: x.double().requires_grad_(True) for k, x in params.items()}
+    vrow = (torch.arange(M) // rows_per_ray) % view_rows
+
+    def model64(mean64, gates=None):
+        enc = orc.integrated_pos_enc(mean64.view(M, 1, 3), cov.double().view(M, 1, 3), 0, 16)
+        venc = orc.pos_enc(vd.double()[vrow], 0, 4)
+        if gates is not None:
+            with orc.forced_gates([gates]):
+                return orc.mlp_forward(p64, enc, venc), enc
+        return orc.mlp_forward(p64, enc, venc), enc
+
+    with torch.no_grad():
+        (raw_rgb64, raw_den64), enc64 = model64(mean.double())
+    assert rel(t32_rows(enc_t, Mp, 96)[:M].cpu(), enc64.view(M, 96)) < 2e-6
+    assert rel(rr.cpu(), raw_rgb64.view(M, 3)) < 1e-5 and rel(rd.cpu(), raw_den64.view(M, nc)) < 1e-5
+    h7 = t32_rows(acts_t[7 * Mp * 256:8 * Mp * 256], Mp, 256)[:M]
+    gates = gates_of(ev, True)
+    assert bool((gates[7] == (h7 > 0).cpu()).all())  # the recorded gate bits are the signs of the stored activations
+
+    # ---- gate-consistent fp64 autograd of L = <d_rgb, raw_rgb> + <d_den, raw_den> + <v, d sigma / d mean>
+    mean64 = mean.double().requires_grad_(True)
+    with torch.enable_grad():
+        (rgb_g, den_g), _ = model64(mean64, gates.view(9, M, 1, 256))
+        sigma = torch.nn.functional.softplus(den_g[..., :1] + dbias)
+        (gmean64,) = torch.autograd.grad(sigma.sum(), mean64, create_graph=True)
+        L = (rgb_g.view(M, 3) * d_rgb.double()).sum() + (den_g.view(M, nc) * d_den.double()).sum() + (gmean64 * v.double()).sum()
+        grads64 = torch.autograd.grad(L, list(p64.values()) + [mean64])
+    by_name = dict(zip(p64.keys(), grads64[:-1]))
+    dmean64 = grads64[-1]
+
+    # ---- kernels
+    rs_t, gmean = E(8, Mp * 256), E(M, 3)
+    _lib.call("pn_chain_density_grad", M, nc, planes, dbias, flat_d.data_ptr(), pack.data_ptr(), mean_d.data_ptr(),
+              cov_d.data_ptr(), ev.masks.data_ptr(), rd.data_ptr(), rs_t.data_ptr(), gmean.data_ptr(), st())
+    assert rel(gmean.cpu(), gmean64.detach()) < 1e-5
+    v_d, drgb_d, dden_d = v.to(dev()), d_rgb.to(dev()), d_den.to(dev())
+    edot_t, tang_t, sdot = E(Mp * 96), E(8, Mp * 256), E(M)
+    _lib.call("pn_chain_tangent", M, nc, planes, flat_d.data_ptr(), pack.data_ptr(), mean_d.data_ptr(), cov_d.data_ptr(),
+              ev.masks.data_ptr(), v_d.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), sdot.data_ptr(), st())
+    drgb_t, dhv_t, d8_t, delta_t, coef_t = Z(Mp * 32), E(Mp * 128), Z(Mp * 288), E(8, Mp * 256), Z(Mp * 32)
+    d_mean = E(M, 3)
+    _lib.call("pn_chain_backward", M, nc, planes, dbias, pack.data_ptr(), ev.masks.data_ptr(), rd.data_ptr(), drgb_d.data_ptr(),
+              dden_d.data_ptr(), sdot.data_ptr(), mean_d.data_ptr(), cov_d.data_ptr(), drgb_t.data_ptr(), dhv_t.data_ptr(),
+              d8_t.data_ptr(), delta_t.data_ptr(), coef_t.data_ptr(), d_mean.data_ptr(), st())
+    grads = Z(total)
+    wfl = int(lib.pn_chain_wgrad_work_floats())
+    work = E(wfl)
+    evc = EvalC(M, enc_t.data_ptr(), acts_t.data_ptr(), drgb_t.data_ptr(), dhv_t.data_ptr(), d8_t.data_ptr(), delta_t.data_ptr(),
+                rs_t.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), coef_t.data_ptr())
+    lib.pn_chain_wgrad.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int64, ctypes.c_void_p]
+    _lib.check(lib.pn_chain_wgrad(1, ctypes.byref(evc), nc, planes, grads.data_ptr(), work.data_ptr(), wfl, st()), "pn_chain_wgrad")
+    torch.cuda.synchronize()
+    # d L / d mean of the first-order part only is what pn_chain_backward returns (the second-order part of d/d mean is
+    # not on the training path: v multiplies a quantity whose mean-derivative nothing consumes)
+    with torch.enable_grad():
+        (rgb_g, den_g), _ = model64(mean64, gates.view(9, M, 1, 256))
+        sig = torch.nn.functional.softplus(den_g[..., :1] + dbias)
+        (gm,) = torch.autograd.grad(sig.sum(), mean64, create_graph=True)
+        sd = (gm * v.double()).sum()  # its derivative w.r.t. raw_density[:, 0] is the softplus'' addend the kernel applies
+        (dz,) = torch.autograd.grad(sd, den_g, retain_graph=True)
+        L1 = (rgb_g.view(M, 3) * d_rgb.double()).sum() + (den_g.view(M, nc) * (d_den.double() + dz.view(M, nc).detach())).sum()
+        (dmean_first,) = torch.autograd.grad(L1, mean64)
+    assert rel(d_mean.cpu(), dmean_first) < 2e-5
+    got = grads.cpu().numpy().astype(np.float64)
+    worst = 0.0
+    for k in ORDER:
+        lo = offs[k]
+        r = by_name[k].detach().numpy().reshape(-1)
+        e = rel(got[lo:lo + r.size], r)
+        worst = max(worst, e)
+        assert e < 2e-5, (k, e)
+    print(f"chain kernels vs fp64 autograd (M={M}, nc={nc}): worst gradient tensor error {worst:.2e}")

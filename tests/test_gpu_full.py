@@ -76,23 +76,30 @@ def check_tuple(outs, g, prefix, names, g64=None):
 
 
 def check_grads(model, g, prefix):
+    """Per-tensor summaries captured by make_golden.py (norm + 256 sampled entries).  The full-gradient gates — every
+    entry of every tensor, fp32 and fp64 references, gate-consistent pointwise parity — are in tests/test_gpu_grads.py."""
     for k, p in model.mlp.named_parameters():
         ref_norm = float(g[f"{prefix}/grad/{k}/norm"])
         got = p.grad.detach().cpu().reshape(-1)
         assert torch.isfinite(got).all(), k
-        assert abs(float(got.double().norm()) - ref_norm) < 2e-2 * ref_norm + 1e-9, (k, float(got.double().norm()), ref_norm)
+        assert abs(float(got.double().norm()) - ref_norm) < 2e-3 * ref_norm + 1e-9, (k, float(got.double().norm()), ref_norm)
         idx, ref = g[f"{prefix}/grad/{k}/idx"], g[f"{prefix}/grad/{k}/val"]
         err = np.abs(got[idx].numpy() - ref)
-        assert float(np.median(err)) < 1e-3 * max(float(np.max(np.abs(ref))), 1e-12), (k, float(np.median(err)))
+        assert float(np.median(err)) < 1e-4 * max(float(np.max(np.abs(ref))), 1e-12), (k, float(np.median(err)))
 
 
+MODES = ["fused", "layerwise"]  # on-chip chains with the exact 3-term bf16 split (default) / one fp32-MFMA GEMM per layer
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", CASES)
-def test_pano_forward_loss_grads(golden, case):
+def test_pano_forward_loss_grads(golden, case, mode):
     import pano_nerf_amd as pn
     g, s = golden("pano_full_" + case), golden("stages_" + case)
     N = s["t_det"].shape[1] - 1
     rays, env = to_dev(rays_of(s)), to_dev(env_of(golden))
     model = make_pano(N)
+    model.mlp_mode = mode
     with torch.no_grad():
         outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
     assert isinstance(outs, list) and len(outs) == 2 and all(len(t) == 9 for t in outs)
@@ -116,13 +123,15 @@ def test_pano_forward_loss_grads(golden, case):
     assert all(v is None for v in outs2[0][2:])
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", CASES)
-def test_mip_forward_loss_grads(golden, case):
+def test_mip_forward_loss_grads(golden, case, mode):
     import pano_nerf_amd as pn
     g, s = golden("mip_full_" + case), golden("stages_" + case)
     N = s["t_det"].shape[1] - 1
     rays = to_dev(rays_of(s))
     model = make_pano(N, nc=1)
+    model.mlp_mode = mode
     names = ("comp_rgb", "distance", "ort_loss", "normal")
     for mode, use_ort in (("val", True), ("valno", False)):
         with torch.no_grad():
@@ -254,43 +263,6 @@ def test_state_dict_and_errors():
     with pytest.raises(RuntimeError, match="no CPU"):
         pn.MipNeRF(num_samples=8, rgb_activation="softplus")(rays=rays, randomized=False, white_bkgd=False,
                                                              use_ort_loss=False)
-
-
-def test_split_gemm_mode_parity(golden):
-    """The optional 3-term bf16-split GEMM mode (pn_set_gemm_mode(1): six v_mfma_f32_32x32x16_bf16 per product,
-    fp32 accumulate) must meet the same parity gates as the exact fp32-MFMA default."""
-    import pano_nerf_amd as pn
-    from pano_nerf_amd import _lib
-    _lib.load().pn_set_gemm_mode(1)
-    try:
-        case = "B64_N32"
-        g, s = golden("pano_full_" + case), golden("stages_" + case)
-        N = s["t_det"].shape[1] - 1
-        rays, env = to_dev(rays_of(s)), to_dev(env_of(golden))
-        model = make_pano(N)
-        with torch.no_grad():
-            outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
-        check_tuple(outs, g, "val", NAMES9, g64=g)
-        model.noise_override = dict(t_rand=torch.from_numpy(g["train_t_rand"]), u_rand=torch.from_numpy(g["train_u_rand"]),
-                                    env_rand=torch.from_numpy(g["train_env_rand"]))
-        outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
-        check_tuple(outs, g, "train", NAMES9)
-        loss, _ = pn.pano_loss(outs, rays.lossmult, torch.from_numpy(s["rgbs"]).to(dev()))
-        assert abs(float(loss) - float(g["train/loss"])) < 1e-4 * abs(float(g["train/loss"]))
-        loss.backward()
-        check_grads(model, g, "train")
-        # operand values across 30 binades keep fp32 accuracy (the split is exact, the dropped terms are <= 2^-24)
-        gen = torch.Generator().manual_seed(1)
-        A = torch.randn(512, 256, generator=gen) * torch.exp2(torch.randint(-15, 15, (512, 1), generator=gen).float())
-        Bt = torch.randn(256, 256, generator=gen)
-        ref = A.double() @ Bt.double().T
-        dA, dB, C = A.to(dev()), Bt.to(dev()), torch.empty(512, 256, device=dev())
-        _lib.call("pn_gemm_nt", 512, 256, 256, dA.data_ptr(), 256, dB.data_ptr(), 256, C.data_ptr(), 256, None, None, 0, 0,
-                  torch.cuda.current_stream().cuda_stream)
-        err = (C.cpu().double() - ref).abs() / (A.double().abs() @ Bt.double().abs().T)
-        assert float(err.max()) < 3e-7, float(err.max())
-    finally:
-        _lib.load().pn_set_gemm_mode(0)
 
 
 def test_autocast_call_pattern_is_fp32_inside(golden):
