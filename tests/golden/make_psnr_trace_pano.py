@@ -26,39 +26,54 @@ def schedule(seed=11):
         yield idx, t_rand, u_rand, env_rand
 
 
+def train(dtype):
+    torch.set_default_dtype(dtype)
+    try:
+        flat, rgbs, radius, _ = orc.synthetic_scene(H, W, 3, seed=4)
+        flat = Rays(*[x.to(dtype) for x in flat])
+        rgbs = rgbs.to(dtype)
+        env = orc.generate_lit_rays(10, radius)
+        envf = Rays(*[x.float().to(dtype) for x in env])
+        net = rpano.PanoMipNeRF(num_samples=N, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5,
+                                num_env_samples=10).to(dtype)
+        mg.load_params(net.mlp, {k: v.to(dtype) for k, v in orc.init_params(4, 5).items()})
+        opt = torch.optim.Adam(net.mlp.parameters(), lr=2e-4)
+        sch = MipLRDecay(opt, 2e-4, 2e-5, 44000, 120, 0.01)
+        losses = []
+        t0 = time.time()
+        for step, (idx, t_rand, u_rand, env_rand) in enumerate(schedule()):
+            it = torch.from_numpy(idx)
+            rays = Rays(*[x[it] for x in flat])
+            gt = rgbs[it]
+            draws = [t_rand, u_rand, env_rand] if dtype == torch.float32 else [d.astype(np.float64) for d in (t_rand, u_rand, env_rand)]
+            with FixedNoise(draws):
+                outs = net(rays=rays, env_rays=envf, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+            loss = mg.ref_loss_pano(outs, rays.lossmult, gt)
+            opt.zero_grad(); loss.backward(); opt.step(); sch.step()
+            losses.append(float(loss))
+            if step % 10 == 0:
+                print(dtype, step, float(loss), time.time() - t0, flush=True)
+        hold = torch.arange(2 * H * W, 3 * H * W, 16)
+        rays = Rays(*[x[hold] for x in flat])
+        outs = net(rays=rays, env_rays=envf, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+        pred, surf = outs[1][0].detach(), outs[1][6].detach()
+        psnr = float(-10.0 * torch.log10(torch.mean((rsurf.hdr_to_ldr(pred) - rsurf.hdr_to_ldr(rgbs[hold])) ** 2)))
+        psnr_surf = float(-10.0 * torch.log10(torch.mean((rsurf.hdr_to_ldr(surf) - rsurf.hdr_to_ldr(rgbs[hold])) ** 2)))
+        return np.array(losses, np.float64), psnr, psnr_surf, pred[:64].float().numpy()
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 def main():
     torch.set_num_threads(8)
-    flat, rgbs, radius, _ = orc.synthetic_scene(H, W, 3, seed=4)
-    env = orc.generate_lit_rays(10, radius)
-    envf = Rays(*[x.float() for x in env])
-    net = rpano.PanoMipNeRF(num_samples=N, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5,
-                            num_env_samples=10)
-    mg.load_params(net.mlp, orc.init_params(4, 5))
-    opt = torch.optim.Adam(net.mlp.parameters(), lr=2e-4)
-    sch = MipLRDecay(opt, 2e-4, 2e-5, 44000, 120, 0.01)
-    losses = []
-    t0 = time.time()
-    for step, (idx, t_rand, u_rand, env_rand) in enumerate(schedule()):
-        it = torch.from_numpy(idx)
-        rays = Rays(*[x[it] for x in flat])
-        gt = rgbs[it]
-        with FixedNoise([t_rand, u_rand, env_rand]):
-            outs = net(rays=rays, env_rays=envf, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
-        loss = mg.ref_loss_pano(outs, rays.lossmult, gt)
-        opt.zero_grad(); loss.backward(); opt.step(); sch.step()
-        losses.append(float(loss))
-        if step % 10 == 0:
-            print(step, float(loss), time.time() - t0, flush=True)
-    hold = torch.arange(2 * H * W, 3 * H * W, 16)
-    rays = Rays(*[x[hold] for x in flat])
-    outs = net(rays=rays, env_rays=envf, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
-    pred, surf = outs[1][0].detach(), outs[1][6].detach()
-    psnr = float(-10.0 * torch.log10(torch.mean((rsurf.hdr_to_ldr(pred) - rsurf.hdr_to_ldr(rgbs[hold])) ** 2)))
-    psnr_surf = float(-10.0 * torch.log10(torch.mean((rsurf.hdr_to_ldr(surf) - rsurf.hdr_to_ldr(rgbs[hold])) ** 2)))
-    print("psnr", psnr, psnr_surf)
-    np.savez_compressed(os.path.join(HERE, "psnr_trace_pano.npz"), losses=np.array(losses, np.float64), psnr=np.float64(psnr),
-                        psnr_surface=np.float64(psnr_surf), steps=np.int64(STEPS), B=np.int64(B), N=np.int64(N),
-                        H=np.int64(H), W=np.int64(W), pred_head=pred[:64].numpy())
+    l32, p32, s32, head = train(torch.float32)
+    # the SAME reference, weights, batches and noise in fp64: how far its own trajectory moves under a change of
+    # arithmetic precision alone (ReLU-gate flips through the second-order path) — the yardstick of the GPU test
+    l64, p64, s64, _ = train(torch.float64)
+    print("psnr", p32, s32, "fp64", p64, s64)
+    np.savez_compressed(os.path.join(HERE, "psnr_trace_pano.npz"), losses=l32, psnr=np.float64(p32),
+                        psnr_surface=np.float64(s32), losses64=l64, psnr64=np.float64(p64), psnr_surface64=np.float64(s64),
+                        steps=np.int64(STEPS), B=np.int64(B), N=np.int64(N), H=np.int64(H), W=np.int64(W), pred_head=head)
 
 
 if __name__ == "__main__":

@@ -70,8 +70,9 @@ def schedule_pano(steps, B, N, H, W, seed=11):
 def test_pano_training_matches_reference_trace(golden, mode):
     """The north-star PSNR target is for the panonerf step: surface + chromaticity + orientation terms, second-order
     gradients (systems/panonerf_system.py:15-75).  Same weights, batches and all three noise draws as the imported
-    reference was trained with on CPU (tests/golden/make_psnr_trace_pano.py): first 20 losses within 2e-3, no drift of
-    the curve, held-out-view PSNR within 0.1 dB."""
+    reference was trained with on CPU (tests/golden/make_psnr_trace_pano.py).  Gates: the loss curve stays as close to the
+    reference's as the reference's own fp64 run does (x1.5; 2e-3 where that is tighter), and the held-out-view PSNR
+    (volume and surface) lies within 0.1 dB of the band spanned by the reference's fp32 and fp64 runs."""
     import pano_nerf_amd as pn
     g = golden("psnr_trace_pano")
     steps, B, N, H, W = (int(g[k]) for k in ("steps", "B", "N", "H", "W"))
@@ -101,17 +102,28 @@ def test_pano_training_matches_reference_trace(golden, mode):
     losses = np.array(losses)
     ref = g["losses"]
     rel = np.abs(losses - ref) / ref
-    assert rel[:20].max() < 2e-3, rel[:20].max()
-    assert np.median(rel) < 2e-2, np.median(rel)
-    assert rel.max() < 0.15, rel.max()
+    # yardstick: the reference against ITSELF in fp64 (same weights, batches, noise): ReLU-gate flips through the
+    # second-order path make this 64-ray training trajectory chaotic — its fp32 and fp64 loss curves part by 1.7e-3 within
+    # 5 steps, 1.1e-2 within 20 and its surface PSNR by 0.11 dB (tests/golden/make_psnr_trace_pano.py)
+    own = np.abs(g["losses"] - g["losses64"]) / g["losses64"]
+    print(f"pano trace {mode}: rel loss error steps 0-4 {rel[:5].max():.2e}, 0-19 {rel[:20].max():.2e}, median {np.median(rel):.2e}, "
+          f"max {rel.max():.2e}   (reference fp32 vs fp64: {own[:5].max():.2e}, {own[:20].max():.2e}, {np.median(own):.2e}, "
+          f"{own.max():.2e})")
+    assert rel[:5].max() < max(2e-3, 1.5 * own[:5].max()), rel[:5].max()
+    assert rel[:20].max() < max(2e-3, 1.5 * own[:20].max()), rel[:20].max()
+    assert np.median(rel) < max(2e-3, 1.5 * np.median(own)), np.median(rel)
+    assert rel.max() < max(2e-2, 1.5 * own.max()), rel.max()
     hold = torch.arange(2 * H * W, 3 * H * W, 16, device=dev)
     model.noise_override = None
     with torch.no_grad():
         outs = model(rays=pn.Rays(*[x[hold] for x in flat_d]), env_rays=env, randomized=False, white_bkgd=False,
                      enable_surf=True, use_ort_loss=True)
     psnr = pn.loss.hdr_to_ldr_psnr(outs[1][0], rgbs_d[hold])
-    assert abs(psnr - float(g["psnr"])) <= 0.1, (psnr, float(g["psnr"]))
     psnr_s = pn.loss.hdr_to_ldr_psnr(outs[1][6], rgbs_d[hold])
-    assert abs(psnr_s - float(g["psnr_surface"])) <= 0.1, (psnr_s, float(g["psnr_surface"]))
-    print(f"pano trace {mode}: first-20 max rel {rel[:20].max():.2e}, median rel {np.median(rel):.2e}, "
-          f"PSNR {psnr:.3f} (reference {float(g['psnr']):.3f}), surface PSNR {psnr_s:.3f} ({float(g['psnr_surface']):.3f})")
+    print(f"pano trace {mode}: PSNR {psnr:.3f} (reference fp32 {float(g['psnr']):.3f}, fp64 {float(g['psnr64']):.3f}), surface PSNR "
+          f"{psnr_s:.3f} ({float(g['psnr_surface']):.3f}, {float(g['psnr_surface64']):.3f})")
+    # within 0.1 dB of the reference, whose own fp32 and fp64 runs bracket the admissible band
+    lo, hi = sorted((float(g["psnr"]), float(g["psnr64"])))
+    assert lo - 0.1 <= psnr <= hi + 0.1, (psnr, lo, hi)
+    lo, hi = sorted((float(g["psnr_surface"]), float(g["psnr_surface64"])))
+    assert lo - 0.1 <= psnr_s <= hi + 0.1, (psnr_s, lo, hi)
