@@ -178,41 +178,62 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
 // consumed before), then refill the slot that chunk just vacated with the chunk D ahead.
 template <int NP>
 struct Ring {
-    const unsigned char* src;  // packed chain (global)
+    static constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT;
+    static constexpr int PIECES = CF / CH_WAVES + 1;  // DMA instructions per wave and chunk: CF/4 fragments + a quarter of the aux KB
+    __amdgpu_buffer_rsrc_t rsrc;  // the packed (sub-)chain: the DMA source is descriptor + SGPR offset + lane * 16
     unsigned char* lds;
-    uint32_t lds_addr;         // LDS byte address of `lds`
-    int nchunk;  // chunks per pass over the chain
+    uint32_t lds_addr;            // LDS byte address of `lds`
+    int nchunk;                   // chunks per pass over the chain
     int pf, pslot, cslot;
     int wid, lane;
-    __device__ __forceinline__ void issue() {
-        constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT;
-        const unsigned char* g = src + (int64_t)pf * SLOT + lane * 16;
-        unsigned char* l = lds + pslot * SLOT;
-#pragma unroll
-        for (int i = 0; i < CF / CH_WAVES; ++i) {
-            const int f = wid + CH_WAVES * i;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + f * 1024), (lds_ptr_t)(l + f * 1024), 16, 0, 0);
-        }
-        // the aux KB: every wave moves a quarter (keeps the per-wave DMA count equal: the counted vmcnt relies on it)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (int64_t)pf * SLOT + CF * 1024 + wid * 256 + lane * 4),
-                                         (lds_ptr_t)(l + CF * 1024 + wid * 256), 4, 0, 0);
+    int cur_soff;                 // refill target of the current round (set by acquire; the GEMM steps issue the pieces)
+    unsigned char* cur_lds;
+    __device__ __forceinline__ void begin_round() {
+        cur_soff = pf * SLOT;
+        cur_lds = lds + pslot * SLOT;
         pf = (pf + 1 == nchunk) ? 0 : pf + 1;
         pslot = (pslot + 1 == Cfg<NP>::NSLOT) ? 0 : pslot + 1;
     }
+    // One DMA instruction (LDS-DMA: buffer_load ... lds).  Issued ONE PER GEMM STEP, behind that step's MFMAs, instead of
+    // as a burst behind the barrier: a burst of seven left the matrix pipe idle for ~40 % of a chunk
+    // (profiles/r02_chain_fwd_phase_trace.txt).
+    template <int I>
+    __device__ __forceinline__ void piece() {
+        if constexpr (I < CF / CH_WAVES) {
+            const int f = wid + CH_WAVES * I;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(cur_lds + f * 1024), 16, lane * 16, cur_soff + f * 1024, 0, 0);
+        } else if constexpr (I == CF / CH_WAVES) {
+            const int o = CF * 1024 + wid * 256;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(cur_lds + o), 4, lane * 4, cur_soff + o, 0, 0);
+        }
+    }
+    template <int I0, int STRIDE>
+    __device__ __forceinline__ void pieces_from() {  // pieces I0, I0 + STRIDE, ... of the current round
+        if constexpr (I0 < PIECES) {
+            piece<I0>();
+            pieces_from<I0 + STRIDE, STRIDE>();
+        }
+    }
     __device__ __forceinline__ void start(const unsigned char* s, unsigned char* l, int n, int w, int ln, int first) {
-        src = s; lds = l; nchunk = n; wid = w; lane = ln;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)s, 0, n * SLOT, 0x00020000);
+        lds = l; nchunk = n; wid = w; lane = ln;
         lds_addr = (uint32_t)(uintptr_t)(lds_ptr_t)l;
         pf = first; pslot = 0; cslot = 0;
 #pragma unroll
-        for (int i = 0; i < Cfg<NP>::D; ++i) issue();
+        for (int i = 0; i < Cfg<NP>::D; ++i) {
+            begin_round();
+            pieces_from<0, 1>();
+        }
     }
-    // returns the LDS byte address of the slot of the next chunk
+    // Wait for my share of the oldest chunk in flight, barrier (everyone's share has landed; everyone is done with the
+    // chunk consumed before), open the refill round of the slot that chunk vacated.  Returns the LDS byte address of
+    // the slot of the chunk to consume.
     __device__ __forceinline__ uint32_t acquire() {
         constexpr int N = Cfg<NP>::SHARE * (Cfg<NP>::D - 1);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
         __builtin_amdgcn_s_barrier();
-        issue();
-        const uint32_t p = lds_addr + cslot * Cfg<NP>::SLOT;
+        begin_round();
+        const uint32_t p = lds_addr + cslot * SLOT;
         cslot = (cslot + 1 == Cfg<NP>::NSLOT) ? 0 : cslot + 1;
         return p;
     }
@@ -274,6 +295,8 @@ struct GemmStep {
         wait_a<NP, more ? NP : 0>(a);
         constexpr int ks = KC * CKS + RR / NT, t = RR % NT;
         acc[t] = mfma_split<NP>(a, b[ks], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        R.template pieces_from<RR, PER>();  // this step's share of the refill round opened by the chunk's acquire
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) {
             a = an;
