@@ -146,8 +146,12 @@ def main():
     fused = args.mlp_mode != "layerwise"
     # fused chains: v_mfma_f32_32x32x16_bf16, six products per fp32-equivalent product (split) or one (plain bf16)
     peak_chain = PEAK_BF16_MFMA_TFLOPS / 6.0 if args.mlp_mode == "fused" else PEAK_BF16_MFMA_TFLOPS
-    CLASSES = ((0, "k_gemm_nt"), (1, "k_gemm_tn"), (2, "k_chain_fwd"), (3, "k_chain_dgrad"), (4, "k_chain_tangent"),
-               (5, "k_chain_bwd"), (6, "k_chain_wgrad"))
+    np_ = 3 if args.mlp_mode == "fused" else 1  # template argument of the fused kernels: bf16 planes per operand
+    # names as rocprofv3 prints them (profiles/*_kernel_stats.csv, profiles/r02_pmc_summary.json)
+    CLASSES = ((0, "k_gemm_nt"), (1, "k_gemm_tn"), (2, f"k_chain_fwd<{np_}>"), (3, f"k_chain_dgrad<{np_}>"),
+               (4, f"k_chain_tangent<{np_}>"), (5, f"k_chain_bwd<{np_}>"), (6, f"k_chain_wgrad<{np_}, 2, 4, 4, 2>"),
+               (7, f"k_chain_wgrad<{np_}, 1, 3, 8, 1>"), (8, f"k_chain_wgrad<{np_}, 1, 9, 4, 1>"),
+               (9, f"k_chain_wgrad<{np_}, 1, 2, 1, 4>"), (10, f"k_chain_wgrad<{np_}, 1, 1, 1, 4>"))
 
     def read_prof():
         res = {}

@@ -1339,7 +1339,7 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     double rows = 0;
     for (int i = 0; i < j.nseg; ++i) rows += 16.0 * (double)j.seg[i].nhalf;
     {
-    PnProfScope prof(6, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone (not the slab reduction)
+    PnProfScope prof(6 + j.cfg, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone (not the slab reduction)
     switch (j.cfg) {
         case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a); break;
         case 1: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 8, 1>), grid, dim3(512), 0, s, a); break;

@@ -66,7 +66,8 @@ int pn_launch_gemm_tn(const PnSegTn* segs, int nseg, int N1, int N2, float* C, i
                       int64_t work_avail, hipStream_t s);
 
 // launch timing (pn_prof_enable / pn_prof_read): bracket a launch with HIP events on its stream.  Classes: 0 k_gemm_nt,
-// 1 k_gemm_tn, 2 k_chain_fwd, 3 k_chain_dgrad, 4 k_chain_tangent, 5 k_chain_bwd, 6 k_chain_wgrad
+// 1 k_gemm_tn, 2 k_chain_fwd, 3 k_chain_dgrad, 4 k_chain_tangent, 5 k_chain_bwd, 6..10 k_chain_wgrad (one per tile
+// configuration: 256x256, 256x96, 128x288, 32x256, 32x128)
 struct PnProfScope {
     void* impl;
     PnProfScope(int cls, double flops, hipStream_t s);

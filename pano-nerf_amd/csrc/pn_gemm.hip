@@ -39,7 +39,7 @@ static int g_dbg = 0;
 #endif
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_free_events;
-#define PN_PROF_CLASSES 8
+#define PN_PROF_CLASSES 12
 static double g_prof_ms[PN_PROF_CLASSES] = {0}, g_prof_flops[PN_PROF_CLASSES] = {0};
 static int64_t g_prof_n[PN_PROF_CLASSES] = {0};
 
