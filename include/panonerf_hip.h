@@ -174,8 +174,13 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_dens
  * their reverse / forward-mode passes as ONE kernel per pass: every layer is computed transposed on
  * v_mfma_f32_32x32x16_bf16, a wave carries the activations of its 32 samples from layer to layer in registers, the
  * weights stream through an LDS ring by LDS-DMA.  planes = 3: exact 3-term bf16 split (fp32 accuracy); planes = 1:
- * plain bf16 operands, fp32 accumulate.  Sample-row tensors these kernels exchange are in the "T32" layout:
- * float[Mp/32][F][32] (sample-minor, Mp = pn_pad_rows(M)); gate words are uint32 [9][Mp][8]. */
+ * plain bf16 operands, fp32 accumulate.  Sample-row tensors these kernels exchange are in the "T layout":
+ * float[Mp/tile][F][tile] (sample-minor, tile = pn_chain_tile(), Mp = pn_pad_rows(M)); gate words are uint32 [9][Mp][8]
+ * (per row: tile-dependent lane-group order, see pn_chain.hip; producers and consumers are all in this library). */
+/* samples per block of the sample-minor tensors (= samples per wave of the chain kernels): 16 (v_mfma_f32_16x16x32_bf16,
+ * two waves per SIMD; the build default) or 32 (v_mfma_f32_32x32x16_bf16, -DPN_CHAIN_TILE=32).  Below, "T layout" means
+ * float[Mp / tile][F][tile]. */
+int pn_chain_tile(void);
 int64_t pn_chain_pack_bytes(int planes);
 int pn_chain_pack(const float* params, int num_density_channels, int planes, void* pack, void* stream);
 /* floats of acts_t: h0..h7 [256] x 8, bottleneck | view encoding [288], view hidden [128] */
@@ -184,20 +189,20 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_den
                      const void* pack, const float* mean, const float* cov, const float* viewdirs, float* enc_t,
                      float* acts_t, uint32_t* masks, float* raw_rgb /*[M,3]*/, float* raw_density /*[M,nc]*/,
                      void* stream);
-/* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep; rs_t: T32 [8][Mp*256] */
+/* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep; rs_t: T [8][Mp*256] */
 int pn_chain_density_grad(int64_t M, int num_density_channels, int planes, float density_bias, const float* params,
                           const void* pack, const float* mean, const float* cov, const uint32_t* masks,
                           const float* raw_density, float* rs_t, float* grad_mean /*[M,3]*/, void* stream);
 /* forward-mode tangent sweep along v_gradmean (the double backward of the normals block) */
 int pn_chain_tangent(int64_t M, int num_density_channels, int planes, const float* params, const void* pack,
                      const float* mean, const float* cov, const uint32_t* masks, const float* v_gradmean,
-                     float* edot_t /*T32 [Mp*96]*/, float* tang_t /*T32 [8][Mp*256]*/, float* sdot /*[M]*/, void* stream);
-/* data-gradient chain.  drgb_t T32 [Mp*32], d8_t T32 [Mp*288], coef_t T32 [Mp*32] must be zero-filled by the caller
+                     float* edot_t /*T [Mp*96]*/, float* tang_t /*T [8][Mp*256]*/, float* sdot /*[M]*/, void* stream);
+/* data-gradient chain.  drgb_t T [Mp*32], d8_t T [Mp*288], coef_t T [Mp*32] must be zero-filled by the caller
  * once (the kernel rewrites the rows it owns); sdot / coef_t: second-order path (both or neither); d_mean nullable. */
 int pn_chain_backward(int64_t M, int num_density_channels, int planes, float density_bias, const void* pack,
                       const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
                       const float* d_raw_density, const float* sdot, const float* mean, const float* cov,
-                      float* drgb_t, float* dhv_t /*T32 [Mp*128]*/, float* d8_t, float* delta_t /*T32 [8][Mp*256]*/,
+                      float* drgb_t, float* dhv_t /*T [Mp*128]*/, float* d8_t, float* delta_t /*T [8][Mp*256]*/,
                       float* coef_t, float* d_mean /*[M,3]*/, void* stream);
 /* one evaluation's tensors for the weight gradients (host struct of device pointers) */
 typedef struct PnChainEval {

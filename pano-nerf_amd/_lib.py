@@ -46,6 +46,7 @@ SIGNATURES = {
     "pn_gemm_nt": ("i", "liipipipippiip"),
     "pn_gemm_tn_work_floats": ("l", "lii"),
     "pn_gemm_tn": ("i", "liipipipiipp"),
+    "pn_chain_tile": ("i", ""),
     "pn_chain_pack_bytes": ("l", "i"),
     "pn_chain_pack": ("i", "piipp"),
     "pn_chain_acts_floats": ("l", "l"),

@@ -1,17 +1,26 @@
 // pn_chain.hip — the radiance MLP as FUSED on-chip chains on the bf16 matrix cores (gfx950).
 //
 // Orientation.  Every layer is computed transposed: H_out^T [features x samples] = W [features x K] * H_in^T
-// [K x samples], with v_mfma_f32_32x32x16_bf16.  A 32x32 accumulator tile then holds one SAMPLE per lane column
-// (lane & 31) and 16 FEATURES in its registers (feature = 32t + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)), which is exactly
-// the B-operand shape of the next layer's MFMA (k runs over the registers): a wave owns 32 samples and carries their
-// activations through the whole chain IN REGISTERS.  No activation ever goes through LDS, nothing is re-read from HBM
-// between layers; activations are written out once (the weight-gradient GEMMs need them) in a sample-minor tiled
-// layout ("T32": [sample block of 32][feature][32 samples], so a register of a wave is two full 128-B lines).
+// [K x samples] on the bf16 MFMA.  An accumulator tile then holds one SAMPLE per lane column and FEATURES in its
+// registers, which is exactly the B-operand shape of the next layer's MFMA (k runs over the registers): a wave owns
+// TILE samples and carries their activations through the whole chain IN REGISTERS.  No activation ever goes through LDS,
+// nothing is re-read from HBM between layers; activations are written out once (the weight-gradient GEMMs need them) in
+// a sample-minor tiled layout ("T layout": [sample block of TILE][feature][TILE samples]).
 //
-// Weights are the A operand.  pn_chain_pack lays them out in fragment order (one 1-KB wave fragment per
-// (k-step, feature tile, plane)), cut into uniform chunks that a ring of LDS slots receives by LDS-DMA
-// (global_load_lds_dwordx4), several chunks ahead, across layer and tile boundaries; the four waves of a workgroup (one
-// per SIMD, up to 512 registers each) consume the same chunk for their own 32 samples.
+// Two MFMA shapes share this code (PN_CHAIN_TILE):
+//   TILE = 16: v_mfma_f32_16x16x32_bf16, 16 samples per wave, 96 + 64 registers of activations + accumulators, so TWO
+//              waves fit a SIMD (8 waves per workgroup): one wave's epilogue (ReLU, gate bits, stores, 3-term split),
+//              encoding and DMA issue run under the other's MFMAs.  Default.
+//   TILE = 32: v_mfma_f32_32x32x16_bf16, 32 samples per wave, 192 + 128 registers, one wave per SIMD (4 per workgroup).
+// Both are instances of one index scheme.  With NG = 64 / TILE lane groups, features come in QUAD BLOCKS of QB = 4 NG:
+// lane (sample c, group g) holds features QB*qb + 4g + i (i = 0..3) of quad block qb.  An accumulator tile is ACCQ =
+// TILE / QB consecutive quad blocks (registers 4q + i), a k-step of the B operand is two consecutive quad blocks
+// (elements j = 4 (qb & 1) + i), so "accumulators -> next B operand" is a re-grouping of registers and the weights (A
+// operand) are packed with the matching k order.
+//
+// Weights are the A operand.  pn_chain_pack lays them out in fragment order (one 1-KB wave fragment per (k-step, feature
+// tile, plane)), cut into uniform chunks that a ring of LDS slots receives by LDS-DMA (buffer_load ... lds), several
+// chunks ahead, across layer and tile boundaries; all waves of a workgroup consume the same chunk for their own samples.
 //
 // Arithmetic.  NP = 3: every fp32 operand is split exactly into three bf16 terms (x = h + m + l) and a product is
 // accumulated in fp32 from its six partial products of weight >= 2^-16 (the error is that of an fp32 fma chain);
@@ -28,17 +37,44 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-#define CH_THREADS 256
-#define CH_WAVES 4
+#ifndef PN_CHAIN_TILE
+#define PN_CHAIN_TILE 16
+#endif
 #define HALF_PI_F 1.5707963705062866f
+constexpr int TILE = PN_CHAIN_TILE;  // features per accumulator tile = samples per wave
+static_assert(TILE == 16 || TILE == 32, "PN_CHAIN_TILE is 16 or 32");
+constexpr int NG = 64 / TILE;        // lane groups
+constexpr int QB = 4 * NG;           // features per quad block
+constexpr int KSTEP = 2 * QB;        // features per k-step of the MFMA
+constexpr int ACCQ = TILE / QB;      // quad blocks per accumulator tile
+constexpr int ACCR = 4 * ACCQ;       // accumulator registers per tile
+#ifndef PN_CHAIN_WAVES
+#define PN_CHAIN_WAVES 4
+#endif
+// Waves per workgroup.  TILE 32: 4 (one per SIMD, up to 512 registers).  TILE 16: 4 waves of <= 256 registers and a 3-slot
+// ring, so TWO INDEPENDENT workgroups share a CU: a workgroup-wide barrier per chunk keeps the waves of ONE workgroup in
+// lockstep (8 waves in one workgroup did their epilogues together and gained nothing), two workgroups drift apart and one's
+// epilogue / encoding / DMA issue runs under the other's MFMAs.
+constexpr int CH_WAVES = PN_CHAIN_WAVES;
+constexpr int CH_THREADS = 64 * CH_WAVES;
+constexpr int CH_SAMPLES = CH_WAVES * TILE;                    // samples per workgroup tile
+constexpr int CH_WG_PER_CU = (TILE == 16 && CH_WAVES == 4) ? 2 : 1;
+constexpr int CH_MIN_WAVES = CH_WAVES * CH_WG_PER_CU / 4;      // waves per SIMD (__launch_bounds__)
+typedef float accv __attribute__((ext_vector_type(ACCR)));
+// shapes of the MLP in k-steps / feature tiles
+constexpr int KS_H = 256 / KSTEP, NT_H = 256 / TILE;      // a 256-wide hidden vector
+constexpr int KS_ENC = 96 / KSTEP, NT_ENC = 96 / TILE;    // the 96-feature integrated encoding
+constexpr int KS_PAD = 32 / KSTEP;                        // a 32-feature padded block (view encoding)
+constexpr int KS_C = 128 / KSTEP, NT_C = 128 / TILE;      // the 128-wide view hidden vector
 
 template <int NP>
 struct Cfg {
     static constexpr int CF = NP == 3 ? 24 : 32;       // fragments (1 KB each) per chunk
+    static constexpr int PER = CF / NP;                // GEMM steps (one A fragment set each) per chunk
     static constexpr int SLOT = (CF + 1) * 1024;       // + 1 KB of aux floats (bias) per chunk
-    static constexpr int NSLOT = NP == 3 ? 5 : 4;      // ring slots
+    static constexpr int NSLOT = CH_WG_PER_CU == 2 ? 3 : (NP == 3 ? 5 : 4);  // ring slots
     static constexpr int D = NSLOT - 1;                // chunks in flight ahead of the one being consumed
-    static constexpr int SHARE = CF / CH_WAVES + 1;    // DMA instructions per wave and chunk
+    static constexpr int SHARE = CF / CH_WAVES;        // DMA instructions EVERY wave issues per chunk (waves 0-3 one more)
     static constexpr int LDS_BYTES = SLOT * NSLOT;
 };
 
@@ -47,52 +83,42 @@ struct BFrag {
     bf16x8 p[NP];
 };
 
-// k index (input feature) of element j of lane half h in k-step ks: the order in which an accumulator tile's
-// registers come out (cdna guide, "an accumulator tile as the next MFMA's operand")
-__host__ __device__ constexpr int kmap(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
-// output feature of accumulator register e of tile t on lane half hh
-__host__ __device__ constexpr int fmap(int t, int e, int hh) { return 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh; }
+// feature held by lane group g in position i of quad block qb
+__host__ __device__ constexpr int feat(int qb, int g, int i) { return QB * qb + 4 * g + i; }
+// k index (input feature) of element j of lane group g in k-step ks
+__host__ __device__ constexpr int kmap(int ks, int g, int j) { return feat(2 * ks + (j >> 2), g, j & 3); }
 
 // ----------------------------------------------------------------------------------------------- chain schedules
-// One entry per GEMM of a chain, in execution order.  KS k-steps of 16, NT feature tiles of 32, CKS k-steps per chunk.
-struct LayerShape {
-    int KS, NT, CKS;
-};
-template <int NP>
-__host__ __device__ constexpr int cks_of(int KS, int NT) {
-    int cap = Cfg<NP>::CF / (NT * NP);
-    int best = 1;
-    for (int c = 1; c <= cap && c <= KS; ++c)
-        if (KS % c == 0) best = c;
-    return best;
-}
-
+// One entry per GEMM of a chain, in execution order: KS k-steps, NT feature tiles; its steps (k-step major, tile minor)
+// are cut into chunks of PER steps, the last chunk padded.  Layer 5 ([h4 | enc], K = 352) and the d enc GEMM ([x0 | x5],
+// K = 512) are two accumulating GEMMs each (F_L5 + F_L5E, B_DENC0 + B_DENC1): the second operand is re-split from its
+// stored T tensor when it is needed instead of being held in registers across the layers in between.
 enum {  // forward-direction GEMMs
-    F_L0 = 0, F_L1, F_L2, F_L3, F_L4, F_L5, F_L6, F_L7, F_DEN, F_EXTRA, F_VIEW, F_COLOR, F_COUNT
+    F_L0 = 0, F_L1, F_L2, F_L3, F_L4, F_L5, F_L5E, F_L6, F_L7, F_DEN, F_EXTRA, F_VIEW, F_COLOR, F_COUNT
 };
 enum {  // backward-direction GEMMs
-    B_COLOR = 0, B_VIEW, B_EXTRA, B_L7, B_L6, B_L5, B_L4, B_L3, B_L2, B_L1, B_DENC, B_COUNT
+    B_COLOR = 0, B_VIEW, B_EXTRA, B_L7, B_L6, B_L5, B_L4, B_L3, B_L2, B_L1, B_DENC0, B_DENC1, B_COUNT
 };
 __host__ __device__ constexpr int fwd_ks(int i) {
-    return i == F_L0 ? 6 : i == F_L5 ? 22 : i == F_VIEW ? 18 : i == F_COLOR ? 8 : 16;
+    return (i == F_L0 || i == F_L5E) ? KS_ENC : i == F_VIEW ? KS_H + KS_PAD : i == F_COLOR ? KS_C : KS_H;
 }
-__host__ __device__ constexpr int fwd_nt(int i) { return (i == F_DEN || i == F_COLOR) ? 1 : i == F_VIEW ? 4 : 8; }
-__host__ __device__ constexpr int bwd_ks(int i) { return i == B_COLOR ? 1 : i == B_VIEW ? 8 : i == B_EXTRA ? 17 : i == B_DENC ? 32 : 16; }
-__host__ __device__ constexpr int bwd_nt(int i) { return i == B_COLOR ? 4 : i == B_DENC ? 3 : 8; }
+__host__ __device__ constexpr int fwd_nt(int i) { return (i == F_DEN || i == F_COLOR) ? 1 : i == F_VIEW ? NT_C : NT_H; }
+__host__ __device__ constexpr int bwd_ks(int i) {
+    return i == B_COLOR ? 1 : i == B_VIEW ? KS_C : i == B_EXTRA ? KS_H + 1 : KS_H;
+}
+__host__ __device__ constexpr int bwd_nt(int i) { return i == B_COLOR ? NT_C : (i == B_DENC0 || i == B_DENC1) ? NT_ENC : NT_H; }
 template <int NP>
-__host__ __device__ constexpr int fwd_chunks(int i) { return fwd_ks(i) / cks_of<NP>(fwd_ks(i), fwd_nt(i)); }
-template <int NP>
-__host__ __device__ constexpr int bwd_chunks(int i) { return bwd_ks(i) / cks_of<NP>(bwd_ks(i), bwd_nt(i)); }
+__host__ __device__ constexpr int chunks_of(int KS, int NT) { return (KS * NT + Cfg<NP>::PER - 1) / Cfg<NP>::PER; }
 template <int NP>
 __host__ __device__ constexpr int fwd_chunk0(int i) {
     int c = 0;
-    for (int k = 0; k < i; ++k) c += fwd_chunks<NP>(k);
+    for (int k = 0; k < i; ++k) c += chunks_of<NP>(fwd_ks(k), fwd_nt(k));
     return c;
 }
 template <int NP>
 __host__ __device__ constexpr int bwd_chunk0(int i) {
     int c = 0;
-    for (int k = 0; k < i; ++k) c += bwd_chunks<NP>(k);
+    for (int k = 0; k < i; ++k) c += chunks_of<NP>(bwd_ks(k), bwd_nt(k));
     return c;
 }
 
@@ -105,7 +131,7 @@ struct PackSeg {
     int col0;
 };
 struct PackLayer {
-    int chunk0, KS, NT, CKS;
+    int chunk0, KS, NT;
     int rows_valid;
     int nseg;
     PackSeg seg[2];
@@ -120,7 +146,7 @@ struct PackTable {
 
 template <int NP>
 __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* out) {
-    constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT;
+    constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT, PER = Cfg<NP>::PER;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
     const int64_t fi = gid >> 6;  // fragment slot index over all chunks, CF + 1 per chunk (the last is the aux KB)
@@ -139,14 +165,14 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
         memcpy(dst, v, 16);
         return;
     }
-    const int kc = chunk - L.chunk0;
-    const int p = f % NP, tt = (f / NP) % L.NT, kk = f / (NP * L.NT);
+    const int p = f % NP;
+    const int step = (chunk - L.chunk0) * PER + f / NP;  // k-step major, tile minor
     unsigned short o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (kk < L.CKS) {
-        const int ks = kc * L.CKS + kk;
-        const int i = 32 * tt + (lane & 31), h = lane >> 5;
+    if (step < L.KS * L.NT) {
+        const int ks = step / L.NT, tt = step % L.NT;
+        const int i = TILE * tt + (lane % TILE), g = lane / TILE;
         for (int j = 0; j < 8; ++j) {
-            const int k = kmap(ks, h, j);
+            const int k = kmap(ks, g, j);
             float x = 0.f;
             if (i < L.rows_valid)
                 for (int s = 0; s < L.nseg; ++s) {
@@ -173,20 +199,21 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
 }
 
 // ------------------------------------------------------------------------------------------------ the weight ring
-// All four waves issue their share of every chunk's DMA and all four consume every chunk.  acquire(): wait for my
-// share of the oldest chunk in flight, barrier (everyone's share has landed; everyone is done with the chunk
-// consumed before), then refill the slot that chunk just vacated with the chunk D ahead.
+// All waves issue their share of every chunk's DMA and all consume every chunk.  acquire(): wait for my share of the
+// oldest chunk in flight, barrier (everyone's share has landed; everyone is done with the chunk consumed before), open
+// the refill round of the slot that chunk vacated; the GEMM steps of the chunk then issue the round's DMA instructions
+// one at a time behind their MFMAs.
 template <int NP>
 struct Ring {
     static constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT;
-    static constexpr int PIECES = CF / CH_WAVES + 1;  // DMA instructions per wave and chunk: CF/4 fragments + a quarter of the aux KB
+    static constexpr int PIECES = CF / CH_WAVES + 1;  // per wave and chunk: CF / waves fragments, + (waves 0-3) a quarter of the aux KB
     __amdgpu_buffer_rsrc_t rsrc;  // the packed (sub-)chain: the DMA source is descriptor + SGPR offset + lane * 16
     unsigned char* lds;
     uint32_t lds_addr;            // LDS byte address of `lds`
     int nchunk;                   // chunks per pass over the chain
     int pf, pslot, cslot;
     int wid, lane;
-    int cur_soff;                 // refill target of the current round (set by acquire; the GEMM steps issue the pieces)
+    int cur_soff;                 // refill target of the current round
     unsigned char* cur_lds;
     __device__ __forceinline__ void begin_round() {
         cur_soff = pf * SLOT;
@@ -194,17 +221,16 @@ struct Ring {
         pf = (pf + 1 == nchunk) ? 0 : pf + 1;
         pslot = (pslot + 1 == Cfg<NP>::NSLOT) ? 0 : pslot + 1;
     }
-    // One DMA instruction (LDS-DMA: buffer_load ... lds).  Issued ONE PER GEMM STEP, behind that step's MFMAs, instead of
-    // as a burst behind the barrier: a burst of seven left the matrix pipe idle for ~40 % of a chunk
-    // (profiles/r02_chain_fwd_phase_trace.txt).
     template <int I>
     __device__ __forceinline__ void piece() {
         if constexpr (I < CF / CH_WAVES) {
             const int f = wid + CH_WAVES * I;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(cur_lds + f * 1024), 16, lane * 16, cur_soff + f * 1024, 0, 0);
         } else if constexpr (I == CF / CH_WAVES) {
-            const int o = CF * 1024 + wid * 256;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(cur_lds + o), 4, lane * 4, cur_soff + o, 0, 0);
+            if (wid < 4) {  // wave-uniform
+                const int o = CF * 1024 + wid * 256;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(cur_lds + o), 4, lane * 4, cur_soff + o, 0, 0);
+            }
         }
     }
     template <int I0, int STRIDE>
@@ -225,9 +251,6 @@ struct Ring {
             pieces_from<0, 1>();
         }
     }
-    // Wait for my share of the oldest chunk in flight, barrier (everyone's share has landed; everyone is done with the
-    // chunk consumed before), open the refill round of the slot that chunk vacated.  Returns the LDS byte address of
-    // the slot of the chunk to consume.
     __device__ __forceinline__ uint32_t acquire() {
         constexpr int N = Cfg<NP>::SHARE * (Cfg<NP>::D - 1);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
@@ -244,25 +267,28 @@ struct Ring {
 };
 
 // ------------------------------------------------------------------------------------------------------ the GEMM
+__device__ __forceinline__ accv mfma1(const bf16x8& a, const bf16x8& b, accv v) {
+#if PN_CHAIN_TILE == 32
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, v, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, v, 0, 0, 0);
+#endif
+}
 template <int NP>
-__device__ __forceinline__ f32x16 mfma_split(const BFrag<NP>& a, const BFrag<NP>& b, f32x16 v) {
+__device__ __forceinline__ accv mfma_split(const BFrag<NP>& a, const BFrag<NP>& b, accv v) {
     if constexpr (NP == 3) {  // small terms first
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
+        v = mfma1(a.p[2], b.p[0], v);
+        v = mfma1(a.p[0], b.p[2], v);
+        v = mfma1(a.p[1], b.p[1], v);
+        v = mfma1(a.p[1], b.p[0], v);
+        v = mfma1(a.p[0], b.p[1], v);
+        v = mfma1(a.p[0], b.p[0], v);
     } else {
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
+        v = mfma1(a.p[0], b.p[0], v);
     }
     return v;
 }
 
-// acc[t] (+)= W-chunks * b[0..KS).  The first chunk's aux KB holds the layer's bias (when BIAS): it initialises the
-// accumulators (register e of tile t <- bias[fmap(t, e, hh)]).  The A fragments of step s + 1 (a step = one
-// (k-step, feature tile) pair, 2 NP MFMAs) are read from LDS before the MFMAs of step s are issued, across chunk
-// boundaries too: the next chunk is acquired while the last fragments of the current one are already in registers.
 // A-fragment reads are inline asm with hand-counted waits: hipcc's own counting turned every other step's wait into
 // lgkmcnt(0), which also waits for the reads just issued for the NEXT step (an LDS latency exposed per two steps).
 template <int NP, int IDX>
@@ -279,63 +305,69 @@ __device__ __forceinline__ void wait_a(BFrag<NP>& a) {
     else
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a.p[0]) : "n"(LEFT) : "memory");
 }
-template <int NP, int KS, int NT, int CKS, int KC, int RR>
+// step S0 of a GEMM of KS x NT steps (k-step major): fragments of step S0 + 1 are read before the MFMAs of step S0, across
+// chunk boundaries too (the next chunk is acquired while the last fragments of the current one are in registers)
+template <int NP, int KS, int NT, int S0>
 struct GemmStep {
-    static __device__ __forceinline__ void run(Ring<NP>& R, const BFrag<NP> (&b)[KS], f32x16 (&acc)[NT], uint32_t& sa,
+    static __device__ __forceinline__ void run(Ring<NP>& R, const BFrag<NP> (&b)[KS], accv (&acc)[NT], uint32_t& sa,
                                                BFrag<NP>& a, int lane) {
-        constexpr int PER = CKS * NT, NCH = KS / CKS;
-        constexpr bool in_chunk = RR + 1 < PER, more = in_chunk || (KC + 1 < NCH);
+        constexpr int PER = Cfg<NP>::PER, S = KS * NT;
+        constexpr int r = S0 % PER;                                   // position in the chunk
+        constexpr int csteps = (S0 / PER == (S - 1) / PER && S % PER) ? S % PER : PER;  // steps of this chunk
+        constexpr bool more = S0 + 1 < S, in_chunk = r + 1 < PER;
         BFrag<NP> an;
-        if constexpr (in_chunk) {
-            read_a<NP, RR + 1>(an, sa);
-        } else if constexpr (more) {
-            sa = R.acquire() + lane * 16;
-            read_a<NP, 0>(an, sa);
+        if constexpr (more) {
+            if constexpr (in_chunk) {
+                read_a<NP, r + 1>(an, sa);
+            } else {
+                sa = R.acquire() + lane * 16;
+                read_a<NP, 0>(an, sa);
+            }
         }
         wait_a<NP, more ? NP : 0>(a);
-        constexpr int ks = KC * CKS + RR / NT, t = RR % NT;
+        constexpr int ks = S0 / NT, t = S0 % NT;
         acc[t] = mfma_split<NP>(a, b[ks], acc[t]);
         __builtin_amdgcn_sched_barrier(0);
-        R.template pieces_from<RR, PER>();  // this step's share of the refill round opened by the chunk's acquire
+        // this step's share of the refill round its chunk's acquire opened.  Careful: when the NEXT chunk was just
+        // acquired above (r + 1 == PER), the round now open belongs to that chunk: its pieces start with its own steps.
+        if constexpr (in_chunk || !more) R.template pieces_from<r, csteps>();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) {
             a = an;
-            GemmStep<NP, KS, NT, CKS, in_chunk ? KC : KC + 1, in_chunk ? RR + 1 : 0>::run(R, b, acc, sa, a, lane);
+            GemmStep<NP, KS, NT, S0 + 1>::run(R, b, acc, sa, a, lane);
         }
     }
 };
 // acc[t] (+)= W-chunks * b[0..KS).  The first chunk's aux KB holds the layer's bias (when BIAS): it initialises the
-// accumulators (register e of tile t <- bias[fmap(t, e, hh)]).  The A fragments of step s + 1 (a step = one
-// (k-step, feature tile) pair, 2 NP MFMAs) are read from LDS before the MFMAs of step s are issued, across chunk
-// boundaries too: the next chunk is acquired while the last fragments of the current one are already in registers.
+// accumulators (position i of quad block qb <- bias[feat(qb, g, i)]).
 template <int NP, int KS, int NT, bool BIAS, bool ZERO>
-__device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS], f32x16 (&acc)[NT], int lane) {
-    constexpr int CKS = cks_of<NP>(KS, NT);
+__device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS], accv (&acc)[NT], int lane) {
     constexpr int CF = Cfg<NP>::CF;
+    static_assert(Ring<NP>::PIECES < Cfg<NP>::PER, "the last step of a full chunk issues no DMA piece");
     const uint32_t s0 = R.acquire();
     if constexpr (BIAS) {
-        const float* aux = reinterpret_cast<const float*>(R.lds + (s0 - R.lds_addr) + CF * 1024) + 4 * (lane >> 5);
+        const float* aux = reinterpret_cast<const float*>(R.lds + (s0 - R.lds_addr) + CF * 1024) + 4 * (lane / TILE);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(aux + 32 * t + 8 * g);
-                acc[t][4 * g] = v[0];
-                acc[t][4 * g + 1] = v[1];
-                acc[t][4 * g + 2] = v[2];
-                acc[t][4 * g + 3] = v[3];
+            for (int q = 0; q < ACCQ; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(aux + QB * (ACCQ * t + q));
+                acc[t][4 * q] = v[0];
+                acc[t][4 * q + 1] = v[1];
+                acc[t][4 * q + 2] = v[2];
+                acc[t][4 * q + 3] = v[3];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not see the asm reads that follow
     } else if constexpr (ZERO) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            for (int e = 0; e < ACCR; ++e) acc[t][e] = 0.f;
     }
     uint32_t sa = s0 + lane * 16;
     BFrag<NP> a;
     read_a<NP, 0>(a, sa);
-    GemmStep<NP, KS, NT, CKS, 0, 0>::run(R, b, acc, sa, a, lane);
+    GemmStep<NP, KS, NT, 0>::run(R, b, acc, sa, a, lane);
 }
 
 // --------------------------------------------------------------------------------------------- register plumbing
@@ -353,54 +385,91 @@ __device__ __forceinline__ void split_into(const float (&x)[8], BFrag<NP>& f) {
         }
     }
 }
-// accumulator tile t -> k-steps 2t, 2t+1 of the next B operand
-template <int NP>
-__device__ __forceinline__ void acc_to_b(const f32x16& a, BFrag<NP>& b0, BFrag<NP>& b1) {
-    float lo[8], hi[8];
+// value at position i of quad block qb of a vector held as accumulator tiles
+#define AQ(acc, qb, i) (acc)[(qb) / ACCQ][4 * ((qb) % ACCQ) + (i)]
+// accumulator tiles (NT tiles = NT * ACCQ / 2 k-steps of quad-block pairs) -> the first k-steps of a B operand
+template <int NP, int NT, int KB>
+__device__ __forceinline__ void acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB]) {
+    constexpr int KS = NT * ACCQ / 2;
+    static_assert((NT * ACCQ) % 2 == 0 && KS <= KB, "quad blocks");
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        lo[j] = a[j];
-        hi[j] = a[8 + j];
+    for (int s = 0; s < KS; ++s) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = AQ(acc, 2 * s + (j >> 2), j & 3);
+        split_into<NP>(x, b[s]);
     }
-    split_into<NP>(lo, b0);
-    split_into<NP>(hi, b1);
 }
-
-// T32 store of one accumulator tile: base points at [block][0][0] + (lane & 31) + 128 * (lane >> 5) floats
-__device__ __forceinline__ void store_tile(float* base, int t, const f32x16& a) {
+// T-layout store: base points at [block][0][0] + (lane % TILE) + 4 * (lane / TILE) * TILE floats
+template <int NT>
+__device__ __forceinline__ void store_t(float* base, const accv (&acc)[NT]) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) base[(32 * t + (e & 3) + 8 * (e >> 2)) * 32] = a[e];
+    for (int qb = 0; qb < NT * ACCQ; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base[(QB * qb + i) * TILE] = AQ(acc, qb, i);
 }
 
-// ReLU gate bits of a lane: 4 words; word w covers tiles 2w, 2w+1; bit 16 (t & 1) + e.  Seen from the B operand, the
-// 8 elements of k-step ks of the same lane are byte ks of these 16 bytes.
+// ReLU gate bits of a lane: bit 4 qb + i, (NT * ACCQ) / 8 words (up to 4).  Seen from the B operand, the 8 elements of
+// k-step ks of the same lane are byte ks of these bytes.
+constexpr int MW = 4 / (NG / 2);  // gate words per lane for a 256-wide vector: 4 (TILE 32) or 2 (TILE 16)
+struct Gate {
+    uint32_t w[MW];
+};
 __device__ __forceinline__ uint32_t bit_of(float v) {  // v >= 0: 1 if v > 0
     const uint32_t u = __builtin_bit_cast(uint32_t, v);
     return u < 1u ? u : 1u;
 }
 template <int NT>
-__device__ __forceinline__ void relu_bits(f32x16 (&acc)[NT], uint32_t (&w)[4]) {
+__device__ __forceinline__ void relu_bits(accv (&acc)[NT], Gate& g) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = 0u;
+    for (int i = 0; i < MW; ++i) g.w[i] = 0u;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int qb = 0; qb < NT * ACCQ; ++qb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float v = fmaxf(acc[t][e], 0.f);
-            acc[t][e] = v;
-            w[t >> 1] |= bit_of(v) << (16 * (t & 1) + e);
+        for (int i = 0; i < 4; ++i) {
+            const float x = AQ(acc, qb, i);
+            const float v = fmaxf(x, 0.f);
+            AQ(acc, qb, i) = v;
+            g.w[(4 * qb + i) >> 5] |= bit_of(v) << ((4 * qb + i) & 31);
         }
 }
 template <int NT>
-__device__ __forceinline__ void gate_bits(f32x16 (&acc)[NT], const uint32_t (&w)[4]) {
+__device__ __forceinline__ void gate_bits(accv (&acc)[NT], const Gate& g) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int qb = 0; qb < NT * ACCQ; ++qb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = __builtin_amdgcn_sbfe((int)w[t >> 1], 16 * (t & 1) + e, 1);  // 0 or -1
-            const float x = acc[t][e];  // (a bit_cast applied directly to the vector element reads element 0)
-            acc[t][e] = __int_as_float(__float_as_int(x) & m);
+        for (int i = 0; i < 4; ++i) {
+            const int m = __builtin_amdgcn_sbfe((int)g.w[(4 * qb + i) >> 5], (4 * qb + i) & 31, 1);  // 0 or -1
+            const float x = AQ(acc, qb, i);  // (a bit_cast applied directly to the vector element reads element 0)
+            AQ(acc, qb, i) = __int_as_float(__float_as_int(x) & m);
         }
+}
+// gate words of slot `slot` of this lane's sample: [slot][Mp][NG][MW] u32
+__device__ __forceinline__ Gate load_gate(const uint32_t* masks, int64_t slot, int64_t Mp, int64_t row, int g) {
+    Gate r;
+    const uint32_t* p = masks + ((slot * Mp + row) * 8 + MW * g);
+    if constexpr (MW == 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        r.w[0] = v.x; r.w[1] = v.y;
+    }
+    return r;
+}
+__device__ __forceinline__ void store_gate(uint32_t* masks, int64_t slot, int64_t Mp, int64_t row, int g, const Gate& r) {
+    uint32_t* p = masks + ((slot * Mp + row) * 8 + MW * g);
+    if constexpr (MW == 4) *reinterpret_cast<uint4*>(p) = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+    else *reinterpret_cast<uint2*>(p) = make_uint2(r.w[0], r.w[1]);
+}
+// The gate words of a tile's layers are loaded once, in the order the chain uses them, and consumed from the front:
+// static indices only (a run-time index puts the array in scratch memory).
+template <int N>
+__device__ __forceinline__ Gate pop_front(Gate (&q)[N]) {
+    const Gate m = q[0];
+#pragma unroll
+    for (int i = 0; i + 1 < N; ++i) q[i] = q[i + 1];
+    return m;
 }
 
 #ifdef PN_TRACE_CHAIN  // debug build only (PN_EXTRA=-DPN_TRACE_CHAIN): shader-clock stamps of one wave's second tile
@@ -416,207 +485,7 @@ extern "C" int pn_chain_trace_read(unsigned long long* out) {
 #define TR(i)
 #endif
 
-// ------------------------------------------------------------------------------------------------- forward chain
-struct FwdArgs {
-    int64_t M, nst;        // sample rows, supertiles of 128
-    int rows_per_ray, nc;
-    int64_t view_rows;
-    const unsigned char* pack;
-    const float* mean;     // [M,3]
-    const float* cov;      // [M,3]
-    const float* viewdirs; // [view_rows,3]
-    float* enc_t;          // T32 [96]
-    float* acts_t;         // T32: h0..h7 [256] x 8, then bottleneck + view encoding [288], then view hidden [128]
-    uint32_t* masks;       // [9][Mp][8]
-    float* raw_rgb;        // [M,3]
-    float* raw_den;        // [M,nc]
-    float dbias_unused;
-};
-__host__ __device__ constexpr int64_t act_off(int slot, int64_t Mp) {  // float offset of activation slot in acts_t
-    return slot <= 8 ? (int64_t)slot * Mp * 256 : 8 * Mp * 256 + Mp * 288;
-}
-__host__ __device__ constexpr int64_t acts_floats(int64_t Mp) { return 8 * Mp * 256 + Mp * 288 + Mp * 128; }
-
-template <int NP>
-__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_fwd(FwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, hh = lane >> 5;
-    const int64_t Mp = a.nst * 128;
-    Ring<NP> R;
-    R.start(a.pack, lds, fwd_chunk0<NP>(F_COUNT), wid, lane, 0);
-    for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
-        const int64_t blk = st * 4 + wid;
-        const int64_t row = blk * 32 + c;
-        const int64_t rc = row < a.M ? row : a.M - 1;
-        const int lo = c + 128 * hh;  // lane part of every T32 address
-        TR(0);
-        // ---- integrated positional encoding -> B operand of layer 0 (and of the skip into layer 5)
-        BFrag<NP> benc[6];
-        {
-            float mu[3], cv[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                mu[i] = a.mean[rc * 3 + i];
-                cv[i] = a.cov[rc * 3 + i];
-            }
-            float* et = a.enc_t + blk * (96 * 32) + lo;
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {  // k-steps ks (sin half) and ks + 3 (the same features + 48)
-                float xs[8], xc[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    // feature f = 16 ks + 8 (j >> 2) + (j & 3) + 4 hh: level l = f / 3, channel f % 3
-                    const int f0 = 16 * ks + 8 * (j >> 2) + (j & 3);
-                    const int f = f0 + 4 * hh;
-                    const int l = f / 3, ch = f - 3 * l;
-                    const float sc = (float)(1 << l);
-                    const float m = ch == 0 ? mu[0] : (ch == 1 ? mu[1] : mu[2]);
-                    const float v = ch == 0 ? cv[0] : (ch == 1 ? cv[1] : cv[2]);
-                    const float y = m * sc;
-                    const float e = expf(-0.5f * (v * (sc * sc)));
-                    xs[j] = e * sinf(y);
-                    xc[j] = e * sinf(y + HALF_PI_F);
-                    et[f0 * 32] = xs[j];
-                    et[(48 + f0) * 32] = xc[j];
-                }
-                split_into<NP>(xs, benc[ks]);
-                split_into<NP>(xc, benc[ks + 3]);
-            }
-        }
-        BFrag<NP> bh[16];
-        f32x16 acc[8];
-        uint32_t mw[4];
-        // ---- layer 0
-        TR(1);
-        chain_gemm<NP, 6, 8, true, false>(R, benc, acc, lane);
-        TR(2);
-        auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T32 store, next B operand
-            relu_bits<8>(acc, mw);
-            float* ht = a.acts_t + act_off(slot, Mp) + blk * (256 * 32) + lo;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                store_tile(ht, t, acc[t]);
-                acc_to_b<NP>(acc[t], bh[2 * t], bh[2 * t + 1]);
-            }
-            uint32_t* mp = a.masks + ((int64_t)slot * Mp + blk * 32 + c) * 8 + 4 * hh;
-            *reinterpret_cast<uint4*>(mp) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-        };
-        finish_hidden(0);
-        TR(3);
-        // ---- layers 1..4
-#pragma unroll 1
-        for (int l = 1; l <= 4; ++l) {
-            chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
-            TR(2 + 2 * l);
-            finish_hidden(l);
-            TR(3 + 2 * l);
-        }
-        // ---- layer 5: [h4 | enc]
-        {
-            BFrag<NP> b5[22];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) b5[i] = bh[i];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) b5[16 + i] = benc[i];
-            chain_gemm<NP, 22, 8, true, false>(R, b5, acc, lane);
-            TR(12);
-            finish_hidden(5);
-            TR(13);
-        }
-#pragma unroll 1
-        for (int l = 6; l <= 7; ++l) {
-            chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
-            TR(2 + 2 * l);
-            finish_hidden(l);
-            TR(3 + 2 * l);
-        }
-        // ---- density head (one tile; channels 0..nc-1 are features 0..nc-1)
-        {
-            f32x16 ad[1];
-            chain_gemm<NP, 16, 1, true, false>(R, bh, ad, lane);
-            if (row < a.M) {
-                if (hh == 0) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (e < a.nc) a.raw_den[row * a.nc + e] = ad[0][e];
-                } else if (a.nc > 4) {
-                    a.raw_den[row * a.nc + 4] = ad[0][0];
-                }
-            }
-        }
-        TR(18);
-        // ---- bottleneck (no activation), then the view layer over [bottleneck | view encoding]
-        BFrag<NP> bv[18];
-        {
-            chain_gemm<NP, 16, 8, true, false>(R, bh, acc, lane);
-            TR(19);
-            float* bt = a.acts_t + act_off(8, Mp) + blk * (288 * 32) + lo;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                store_tile(bt, t, acc[t]);
-                acc_to_b<NP>(acc[t], bv[2 * t], bv[2 * t + 1]);
-            }
-            const int64_t vr = (rc / a.rows_per_ray) % a.view_rows;
-            float vd[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) vd[i] = a.viewdirs[vr * 3 + i];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f0 = 16 * q + 8 * (j >> 2) + (j & 3);
-                    const int v = f0 + 4 * hh;  // view-encoding feature 0..31 (27 real)
-                    float o = 0.f;
-                    if (v < 3) {
-                        o = v == 0 ? vd[0] : (v == 1 ? vd[1] : vd[2]);
-                    } else if (v < PN_VIEW_DIM) {
-                        const int i = v - 3, f = i % 12, half = i / 12, l = f / 3, ch = f % 3;
-                        const float xb = (ch == 0 ? vd[0] : (ch == 1 ? vd[1] : vd[2])) * (float)(1 << l);
-                        o = sinf(half ? xb + HALF_PI_F : xb);
-                    }
-                    x[j] = o;
-                    bt[(256 + f0) * 32] = o;
-                }
-                split_into<NP>(x, bv[16 + q]);
-            }
-        }
-        TR(20);
-        BFrag<NP> bc[8];
-        {
-            f32x16 av[4];
-            chain_gemm<NP, 18, 4, true, false>(R, bv, av, lane);
-            TR(21);
-            uint32_t w4[4];
-            relu_bits<4>(av, w4);
-            float* ht = a.acts_t + act_off(9, Mp) + blk * (128 * 32) + lo;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                store_tile(ht, t, av[t]);
-                acc_to_b<NP>(av[t], bc[2 * t], bc[2 * t + 1]);
-            }
-            uint32_t* mp = a.masks + ((int64_t)8 * Mp + blk * 32 + c) * 8 + 4 * hh;
-            *reinterpret_cast<uint4*>(mp) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-        }
-        TR(22);
-        {
-            f32x16 ac[1];
-            chain_gemm<NP, 8, 1, true, false>(R, bc, ac, lane);
-            TR(23);
-            if (row < a.M && hh == 0) {
-#pragma unroll
-                for (int e = 0; e < 3; ++e) a.raw_rgb[row * 3 + e] = ac[0][e];
-            }
-        }
-        TR(24);
-    }
-    R.drain();
-}
-
-
-// ---------------------------------------------------------------------------------- shared pieces of the sweeps
+// ---------------------------------------------------------------------------------- shared pieces of the chains
 __device__ __forceinline__ float ch_sp_d1(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float ch_sp_d2(float x) {
     if (x > 20.f) return 0.f;
@@ -625,59 +494,256 @@ __device__ __forceinline__ float ch_sp_d2(float x) {
 }
 __device__ __forceinline__ float sel3(const float (&v)[3], int ch) { return ch == 0 ? v[0] : (ch == 1 ? v[1] : v[2]); }
 
-// The gate words of a tile's layers are loaded once, in the order the chain uses them, and consumed from the front:
-// static indices only (a run-time index puts the array in scratch memory).
-template <int N>
-__device__ __forceinline__ uint4 pop_front(uint4 (&q)[N]) {
-    const uint4 m = q[0];
-#pragma unroll
-    for (int i = 0; i + 1 < N; ++i) q[i] = q[i + 1];
-    return m;
+// per-lane coordinates of a wave's tile
+struct Tile {
+    int64_t blk, row, rc;  // sample block, sample row, row clamped into [0, M)
+    int c, g, lo;          // sample in the block, lane group, lane part of every T-layout address
+    bool live;
+};
+__device__ __forceinline__ Tile tile_of(int64_t st, int wid, int lane, int64_t M) {
+    Tile t;
+    t.c = lane % TILE;
+    t.g = lane / TILE;
+    t.blk = st * CH_WAVES + wid;
+    t.row = t.blk * TILE + t.c;
+    t.live = t.row < M;
+    t.rc = t.live ? t.row : M - 1;
+    t.lo = t.c + 4 * t.g * TILE;
+    return t;
 }
-// gate, T32 store and next B operand of a 256-wide hidden vector (backward-direction sweeps and the tangent sweep)
-template <int NP>
-__device__ __forceinline__ void finish_gated(f32x16 (&acc)[8], const uint4& m, float* out, BFrag<NP> (&bh)[16]) {
-    const uint32_t w[4] = {m.x, m.y, m.z, m.w};
-    gate_bits<8>(acc, w);
+
+// integrated positional encoding (MODE 0), or its tangent along v (MODE 1), of this lane's 96 / NG features -> T-layout
+// store + B operand.  Features f and f + 48 (sine / "cosine" of the same argument) sit in the same lane.
+template <int NP, int MODE>
+__device__ __forceinline__ void encode(const float (&mu)[3], const float (&cv)[3], const float (&vv)[3], int g, float* et,
+                                       BFrag<NP> (&benc)[KS_ENC]) {
+    constexpr int NQ = 96 / QB;  // quad blocks of the encoding; the first half are the sines
+    float x[NQ][4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) store_tile(out, t, acc[t]);
+    for (int qb = 0; qb < NQ / 2; ++qb)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc_to_b<NP>(acc[t], bh[2 * t], bh[2 * t + 1]);
+        for (int i = 0; i < 4; ++i) {
+            const int f = QB * qb + 4 * g + i;  // level l = f / 3, channel f % 3
+            const int l = f / 3, ch = f - 3 * l;
+            const float sc = (float)(1 << l);
+            const float y = sel3(mu, ch) * sc;
+            const float e0 = expf(-0.5f * (sel3(cv, ch) * (sc * sc)));
+            if constexpr (MODE == 0) {
+                x[qb][i] = e0 * sinf(y);
+                x[qb + NQ / 2][i] = e0 * sinf(y + HALF_PI_F);
+            } else {
+                const float e = e0 * sc * sel3(vv, ch);
+                x[qb][i] = e * cosf(y);
+                x[qb + NQ / 2][i] = e * cosf(y + HALF_PI_F);
+            }
+        }
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) et[(QB * qb + i) * TILE] = x[qb][i];
+#pragma unroll
+    for (int s = 0; s < KS_ENC; ++s) {
+        float y8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y8[j] = x[2 * s + (j >> 2)][j & 3];
+        split_into<NP>(y8, benc[s]);
+    }
 }
-// B operand k-steps [0, 16) <- a stored T32 [256] block of this wave (fp32), e.g. r5 / delta5 for the skip columns
-template <int NP>
-__device__ __forceinline__ void reload_b(const float* src, int hh, BFrag<NP> (&b)[16]) {
+// B operand k-steps <- a stored T-layout block of this wave (fp32): the encoding for the skip columns, r5 / delta5
+template <int NP, int KS>
+__device__ __forceinline__ void reload_b(const float* src, BFrag<NP> (&b)[KS]) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = src[(16 * ks + 8 * (j >> 2) + (j & 3)) * 32];  // + 4 hh rows via the lane offset
+        for (int j = 0; j < 8; ++j) x[j] = src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];  // + 4 g rows via the lane offset
         split_into<NP>(x, b[ks]);
     }
 }
-// d enc (three accumulator tiles: 96 features) -> d mean of this lane's sample; both lane halves end with the sum
-__device__ __forceinline__ void ipe_backward_tiles(const f32x16 (&acc)[3], const float (&mu)[3], const float (&cv)[3], int hh,
+// d enc (accumulator tiles over 96 features) -> d mean of this lane's sample; every lane group ends with the sum
+__device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], const float (&mu)[3], const float (&cv)[3], int g,
                                                    float (&dm)[3]) {
     dm[0] = dm[1] = dm[2] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int qb = 0; qb < 96 / QB; ++qb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int F0 = 32 * t + (e & 3) + 8 * (e >> 2);  // + 4 hh
-            const int F = F0 + 4 * hh;
+        for (int i = 0; i < 4; ++i) {
+            const int F = QB * qb + 4 * g + i;
             const bool cosine = F >= 48;
             const int f = cosine ? F - 48 : F;
             const int l = f / 3, ch = f - 3 * l;
             const float sc = (float)(1 << l);
             const float y = sel3(mu, ch) * sc;
             const float ex = expf(-0.5f * (sel3(cv, ch) * (sc * sc))) * sc;
-            const float g = acc[t][e] * ex * cosf(cosine ? y + HALF_PI_F : y);
-            dm[0] += ch == 0 ? g : 0.f;
-            dm[1] += ch == 1 ? g : 0.f;
-            dm[2] += ch == 2 ? g : 0.f;
+            const float d = AQ(acc, qb, i) * ex * cosf(cosine ? y + HALF_PI_F : y);
+            dm[0] += ch == 0 ? d : 0.f;
+            dm[1] += ch == 1 ? d : 0.f;
+            dm[2] += ch == 2 ? d : 0.f;
         }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dm[i] += __shfl_xor(dm[i], 32, 64);
+    for (int i = 0; i < 3; ++i) {
+        dm[i] += __shfl_xor(dm[i], 32, 64);
+        if constexpr (NG == 4) dm[i] += __shfl_xor(dm[i], 16, 64);
+    }
+}
+// gate, T-layout store and next B operand of a 256-wide hidden vector (backward-direction sweeps and the tangent sweep)
+template <int NP>
+__device__ __forceinline__ void finish_gated(accv (&acc)[NT_H], const Gate& m, float* out, BFrag<NP> (&bh)[KS_H]) {
+    gate_bits<NT_H>(acc, m);
+    store_t<NT_H>(out, acc);
+    acc_to_b<NP, NT_H, KS_H>(acc, bh);
+}
+
+// ------------------------------------------------------------------------------------------------- forward chain
+struct FwdArgs {
+    int64_t M, nst;        // sample rows, workgroup tiles of CH_SAMPLES
+    int rows_per_ray, nc;
+    int64_t view_rows;
+    const unsigned char* pack;
+    const float* mean;     // [M,3]
+    const float* cov;      // [M,3]
+    const float* viewdirs; // [view_rows,3]
+    float* enc_t;          // T [96]
+    float* acts_t;         // T: h0..h7 [256] x 8, then bottleneck + view encoding [288], then view hidden [128]
+    uint32_t* masks;       // [9][Mp][8]
+    float* raw_rgb;        // [M,3]
+    float* raw_den;        // [M,nc]
+};
+__host__ __device__ constexpr int64_t act_off(int slot, int64_t Mp) {  // float offset of activation slot in acts_t
+    return slot <= 8 ? (int64_t)slot * Mp * 256 : 8 * Mp * 256 + Mp * 288;
+}
+__host__ __device__ constexpr int64_t acts_floats(int64_t Mp) { return 8 * Mp * 256 + Mp * 288 + Mp * 128; }
+
+template <int NP>
+__global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t Mp = a.nst * CH_SAMPLES;
+    Ring<NP> R;
+    R.start(a.pack, lds, fwd_chunk0<NP>(F_COUNT), wid, lane, 0);
+    for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
+        const Tile T = tile_of(st, wid, lane, a.M);
+        TR(0);
+        float* et = a.enc_t + T.blk * (96 * TILE) + T.lo;
+        BFrag<NP> bh[KS_H];
+        accv acc[NT_H];
+        Gate mw;
+        {
+            // ---- integrated positional encoding -> B operand of layer 0
+            float mu[3], cv[3];
+            const float zero3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                mu[i] = a.mean[T.rc * 3 + i];
+                cv[i] = a.cov[T.rc * 3 + i];
+            }
+            BFrag<NP> benc[KS_ENC];
+            encode<NP, 0>(mu, cv, zero3, T.g, et, benc);
+            TR(1);
+            chain_gemm<NP, KS_ENC, NT_H, true, false>(R, benc, acc, lane);
+            TR(2);
+        }
+        auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T store, next B operand
+            relu_bits<NT_H>(acc, mw);
+            store_t<NT_H>(a.acts_t + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);
+            store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
+            acc_to_b<NP, NT_H, KS_H>(acc, bh);
+        };
+        finish_hidden(0);
+        TR(3);
+#pragma unroll 1
+        for (int l = 1; l <= 4; ++l) {
+            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            TR(2 + 2 * l);
+            finish_hidden(l);
+            TR(3 + 2 * l);
+        }
+        {  // ---- layer 5: [h4 | enc] as two accumulating GEMMs (F_L5, F_L5E)
+            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            BFrag<NP> benc[KS_ENC];
+            reload_b<NP, KS_ENC>(et, benc);
+            chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane);
+            TR(12);
+            finish_hidden(5);
+            TR(13);
+        }
+#pragma unroll 1
+        for (int l = 6; l <= 7; ++l) {
+            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            TR(2 + 2 * l);
+            finish_hidden(l);
+            TR(3 + 2 * l);
+        }
+        {  // ---- density head (one tile; channel ch is feature ch: quad block 0 of lane group ch / 4)
+            accv ad[1];
+            chain_gemm<NP, KS_H, 1, true, false>(R, bh, ad, lane);
+            if (T.live) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ch = 4 * T.g + i;
+                    if (ch < a.nc) a.raw_den[T.row * a.nc + ch] = ad[0][i];
+                }
+            }
+        }
+        TR(18);
+        // ---- bottleneck (no activation), then the view layer over [bottleneck | view encoding]
+        BFrag<NP> bv[KS_H + KS_PAD];
+        {
+            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            TR(19);
+            float* bt = a.acts_t + act_off(8, Mp) + T.blk * (288 * TILE) + T.lo;
+            store_t<NT_H>(bt, acc);
+            acc_to_b<NP, NT_H, KS_H + KS_PAD>(acc, bv);
+            const int64_t vr = (T.rc / a.rows_per_ray) % a.view_rows;
+            float vd[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) vd[i] = a.viewdirs[vr * 3 + i];
+#pragma unroll
+            for (int q = 0; q < KS_PAD; ++q) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int v = QB * (2 * q + (j >> 2)) + 4 * T.g + (j & 3);  // view-encoding feature 0..31 (27 real)
+                    float o = 0.f;
+                    if (v < 3) {
+                        o = sel3(vd, v);
+                    } else if (v < PN_VIEW_DIM) {
+                        const int i = v - 3, f = i % 12, half = i / 12, l = f / 3, ch = f % 3;
+                        const float xb = sel3(vd, ch) * (float)(1 << l);
+                        o = sinf(half ? xb + HALF_PI_F : xb);
+                    }
+                    x[j] = o;
+                    bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = o;
+                }
+                split_into<NP>(x, bv[KS_H + q]);
+            }
+        }
+        TR(20);
+        BFrag<NP> bc[KS_C];
+        {
+            accv av[NT_C];
+            chain_gemm<NP, KS_H + KS_PAD, NT_C, true, false>(R, bv, av, lane);
+            TR(21);
+            Gate w4;
+            relu_bits<NT_C>(av, w4);
+            store_t<NT_C>(a.acts_t + act_off(9, Mp) + T.blk * (128 * TILE) + T.lo, av);
+            store_gate(a.masks, 8, Mp, T.blk * TILE + T.c, T.g, w4);
+            acc_to_b<NP, NT_C, KS_C>(av, bc);
+        }
+        TR(22);
+        {
+            accv ac[1];
+            chain_gemm<NP, KS_C, 1, true, false>(R, bc, ac, lane);
+            TR(23);
+            if (T.live && T.g == 0) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) a.raw_rgb[T.row * 3 + e] = ac[0][e];
+            }
+        }
+        TR(24);
+    }
+    R.drain();
 }
 
 // ------------------------------------------------------------------------- density-gradient reverse sweep (level 1)
@@ -696,74 +762,70 @@ struct SweepArgs {
     const float* cov;
     const float* wd0;            // density_layer.weight[0] (256 floats, in the parameter block)
     const float* v;              // [M,3] tangent direction (tangent sweep)
-    float* vec_t;                // T32 [8][256]: r_0..r_7 (reverse sweep) or hdot_0..hdot_7 (tangent sweep)
-    float* edot_t;               // T32 [96] (tangent sweep)
+    float* vec_t;                // T [8][256]: r_0..r_7 (reverse sweep) or hdot_0..hdot_7 (tangent sweep)
+    float* edot_t;               // T [96] (tangent sweep)
     float* out3;                 // [M,3] grad_mean (reverse sweep)
     float* sdot;                 // [M] (tangent sweep)
 };
 
 template <int NP>
-__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_dgrad(SweepArgs a) {
+__global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, hh = lane >> 5;
-    const int64_t Mp = a.nst * 128;
+    const int64_t Mp = a.nst * CH_SAMPLES;
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
-        const int64_t blk = st * 4 + wid;
-        const int64_t row = blk * 32 + c;
-        const int64_t rc = row < a.M ? row : a.M - 1;
-        const int lo = c + 128 * hh;
-        uint4 mk[8];  // gates of h7, h6, ..., h0
+        const Tile T = tile_of(st, wid, lane, a.M);
+        Gate mk[8];  // gates of h7, h6, ..., h0
 #pragma unroll
-        for (int l = 0; l < 8; ++l) mk[l] = *reinterpret_cast<const uint4*>(a.masks + ((int64_t)(7 - l) * Mp + blk * 32 + c) * 8 + 4 * hh);
+        for (int l = 0; l < 8; ++l) mk[l] = load_gate(a.masks, 7 - l, Mp, T.blk * TILE + T.c, T.g);
         float mu[3], cv[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            mu[i] = a.mean[rc * 3 + i];
-            cv[i] = a.cov[rc * 3 + i];
+            mu[i] = a.mean[T.rc * 3 + i];
+            cv[i] = a.cov[T.rc * 3 + i];
         }
-        const float sgm = row < a.M ? ch_sp_d1(a.raw_den[rc * a.nc] + a.density_bias) : 0.f;
-        BFrag<NP> bh[16];
+        const float sgm = T.live ? ch_sp_d1(a.raw_den[T.rc * a.nc] + a.density_bias) : 0.f;
+        BFrag<NP> bh[KS_H];
         {  // seed r_7
-            float* rt = a.vec_t + (int64_t)7 * Mp * 256 + blk * (256 * 32) + lo;
-            const uint4 m7 = pop_front(mk);
-            const uint32_t w[4] = {m7.x, m7.y, m7.z, m7.w};
+            float* rt = a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo;
+            const Gate m7 = pop_front(mk);
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
+            for (int ks = 0; ks < KS_H; ++ks) {
                 float x[8];
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.wd0 + 16 * ks + 4 * hh);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.wd0 + 16 * ks + 8 + 4 * hh);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float wv = j < 4 ? w0[j & 3] : w1[j & 3];
-                    const uint32_t bit = (w[ks >> 2] >> (8 * (ks & 3) + j)) & 1u;
-                    x[j] = bit ? sgm * wv : 0.f;
-                    rt[(16 * ks + 8 * (j >> 2) + (j & 3)) * 32] = x[j];
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.wd0 + QB * (2 * ks + h) + 4 * T.g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 4 * h + i;
+                        const uint32_t bit = (m7.w[(8 * ks + j) >> 5] >> ((8 * ks + j) & 31)) & 1u;
+                        x[j] = bit ? sgm * wv[i] : 0.f;
+                        rt[(QB * (2 * ks + h) + i) * TILE] = x[j];
+                    }
                 }
                 split_into<NP>(x, bh[ks]);
             }
         }
-        f32x16 acc[8];
+        accv acc[NT_H];
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
-            chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)(l - 1) * Mp * 256 + blk * (256 * 32) + lo, bh);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
         }
-        {  // d sigma / d enc over [r_0 | r_5], then the encoding's adjoint
-            static_assert(cks_of<NP>(16, 3) == cks_of<NP>(32, 3), "the two halves walk the chunks of one K = 512 GEMM");
-            f32x16 a3[3];
-            chain_gemm<NP, 16, 3, false, true>(R, bh, a3, lane);
-            reload_b<NP>(a.vec_t + (int64_t)5 * Mp * 256 + blk * (256 * 32) + lo, hh, bh);
-            chain_gemm<NP, 16, 3, false, false>(R, bh, a3, lane);
+        {  // d sigma / d enc over [r_0 | r_5] (two accumulating GEMMs: B_DENC0, B_DENC1), then the encoding's adjoint
+            accv a3[NT_ENC];
+            chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane);
+            reload_b<NP, KS_H>(a.vec_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane);
             float dm[3];
-            ipe_backward_tiles(a3, mu, cv, hh, dm);
-            if (row < a.M && hh == 0) {
-                a.out3[row * 3] = dm[0];
-                a.out3[row * 3 + 1] = dm[1];
-                a.out3[row * 3 + 2] = dm[2];
+            ipe_backward_tiles(a3, mu, cv, T.g, dm);
+            if (T.live && T.g == 0) {
+                a.out3[T.row * 3] = dm[0];
+                a.out3[T.row * 3 + 1] = dm[1];
+                a.out3[T.row * 3 + 2] = dm[2];
             }
         }
     }
@@ -774,98 +836,69 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain_dgrad(SweepArgs a) {
 // hdot_l = gate_l * (W_l hdot_{l-1}) from edot = d enc / d mean . v ; sdot = Wd[0] . hdot_7.  With the saved r_l this gives
 // the second-order weight gradients dW_l += r_l^T hdot_{l-1} (the double backward of models/pano_mip_nerf.py:299-313).
 template <int NP>
-__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_tangent(SweepArgs a) {
+__global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, hh = lane >> 5;
-    const int64_t Mp = a.nst * 128;
+    const int64_t Mp = a.nst * CH_SAMPLES;
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
-        const int64_t blk = st * 4 + wid;
-        const int64_t row = blk * 32 + c;
-        const int64_t rc = row < a.M ? row : a.M - 1;
-        const int lo = c + 128 * hh;
-        uint4 mk[8];
+        const Tile T = tile_of(st, wid, lane, a.M);
+        Gate mk[8];
 #pragma unroll
-        for (int l = 0; l < 8; ++l) mk[l] = *reinterpret_cast<const uint4*>(a.masks + ((int64_t)l * Mp + blk * 32 + c) * 8 + 4 * hh);
-        float mu[3], cv[3], vv[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            mu[i] = a.mean[rc * 3 + i];
-            cv[i] = a.cov[rc * 3 + i];
-            vv[i] = row < a.M ? a.v[rc * 3 + i] : 0.f;
-        }
-        BFrag<NP> benc[6];
+        for (int l = 0; l < 8; ++l) mk[l] = load_gate(a.masks, l, Mp, T.blk * TILE + T.c, T.g);
+        float* et = a.edot_t + T.blk * (96 * TILE) + T.lo;
+        BFrag<NP> bh[KS_H];
+        accv acc[NT_H];
         {
-            float* et = a.edot_t + blk * (96 * 32) + lo;
+            float mu[3], cv[3], vv[3];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                float xs[8], xc[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f0 = 16 * ks + 8 * (j >> 2) + (j & 3);
-                    const int f = f0 + 4 * hh;
-                    const int l = f / 3, ch = f - 3 * l;
-                    const float sc = (float)(1 << l);
-                    const float y = sel3(mu, ch) * sc;
-                    const float e = expf(-0.5f * (sel3(cv, ch) * (sc * sc))) * sc * sel3(vv, ch);
-                    xs[j] = e * cosf(y);
-                    xc[j] = e * cosf(y + HALF_PI_F);
-                    et[f0 * 32] = xs[j];
-                    et[(48 + f0) * 32] = xc[j];
-                }
-                split_into<NP>(xs, benc[ks]);
-                split_into<NP>(xc, benc[ks + 3]);
+            for (int i = 0; i < 3; ++i) {
+                mu[i] = a.mean[T.rc * 3 + i];
+                cv[i] = a.cov[T.rc * 3 + i];
+                vv[i] = T.live ? a.v[T.rc * 3 + i] : 0.f;
             }
+            BFrag<NP> benc[KS_ENC];
+            encode<NP, 1>(mu, cv, vv, T.g, et, benc);
+            chain_gemm<NP, KS_ENC, NT_H, false, true>(R, benc, acc, lane);
         }
-        BFrag<NP> bh[16];
-        f32x16 acc[8];
-        chain_gemm<NP, 6, 8, false, true>(R, benc, acc, lane);
-        finish_gated<NP>(acc, pop_front(mk), a.vec_t + blk * (256 * 32) + lo, bh);
+        finish_gated<NP>(acc, pop_front(mk), a.vec_t + T.blk * (256 * TILE) + T.lo, bh);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
-            chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)l * Mp * 256 + blk * (256 * 32) + lo, bh);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)l * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
         }
         {
-            BFrag<NP> b5[22];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) b5[i] = bh[i];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) b5[16 + i] = benc[i];
-            chain_gemm<NP, 22, 8, false, true>(R, b5, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)5 * Mp * 256 + blk * (256 * 32) + lo, bh);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+            BFrag<NP> benc[KS_ENC];
+            reload_b<NP, KS_ENC>(et, benc);
+            chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
         }
-        chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
-        finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)6 * Mp * 256 + blk * (256 * 32) + lo, bh);
-        chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
+        chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+        finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)6 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
         {
-            const uint4 m7 = pop_front(mk);
-            const uint32_t w[4] = {m7.x, m7.y, m7.z, m7.w};
-            gate_bits<8>(acc, w);
-            float* ht = a.vec_t + (int64_t)7 * Mp * 256 + blk * (256 * 32) + lo;
+            gate_bits<NT_H>(acc, pop_front(mk));
+            store_t<NT_H>(a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, acc);
             float sd = 0.f;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                store_tile(ht, t, acc[t]);
+            for (int qb = 0; qb < NT_H * ACCQ; ++qb) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(a.wd0 + QB * qb + 4 * T.g);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.wd0 + 32 * t + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sd += acc[t][4 * g + i] * wv[i];
-                }
+                for (int i = 0; i < 4; ++i) sd += AQ(acc, qb, i) * wv[i];
             }
             sd += __shfl_xor(sd, 32, 64);
-            if (row < a.M && hh == 0) a.sdot[row] = sd;
+            if constexpr (NG == 4) sd += __shfl_xor(sd, 16, 64);
+            if (T.live && T.g == 0) a.sdot[T.row] = sd;
         }
     }
     R.drain();
 }
 
 // ------------------------------------------------------------------------------------------------- backward chain
-// d raw_rgb, d raw_density -> delta of every layer (T32, for the weight-gradient GEMMs) -> optionally d mean.
+// d raw_rgb, d raw_density -> delta of every layer (T layout, for the weight-gradient GEMMs) -> optionally d mean.
 struct BwdArgs {
     int64_t M, nst;
     int nc;
@@ -879,127 +912,111 @@ struct BwdArgs {
     const float* sdot;          // [M] or null: second-order addend softplus''(z) * sdot on channel 0
     const float* mean;
     const float* cov;
-    float* drgb_t;              // T32 [32]
-    float* dhv_t;               // T32 [128]
-    float* d8_t;                // T32 [288]: d bottleneck | d raw_density (padded)
-    float* delta_t;             // T32 [8][256]
-    float* coef_t;              // T32 [32] or null: row 0 = softplus'(z) (second-order dWd[0] term)
+    float* drgb_t;              // T [32]
+    float* dhv_t;               // T [128]
+    float* d8_t;                // T [288]: d bottleneck | d raw_density (padded)
+    float* delta_t;             // T [8][256]
+    float* coef_t;              // T [32] or null: row 0 = softplus'(z) (second-order dWd[0] term)
     float* d_mean;              // [M,3] or null
 };
 
 template <int NP>
-__global__ __launch_bounds__(CH_THREADS, 1) void k_chain_bwd(BwdArgs a) {
+__global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, hh = lane >> 5;
-    const int64_t Mp = a.nst * 128;
+    const int64_t Mp = a.nst * CH_SAMPLES;
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
-        const int64_t blk = st * 4 + wid;
-        const int64_t row = blk * 32 + c;
-        const bool live = row < a.M;
-        const int64_t rc = live ? row : a.M - 1;
-        const int lo = c + 128 * hh;
-        uint4 mk[9];  // gates of the view hidden, h7, h6, ..., h0
+        const Tile T = tile_of(st, wid, lane, a.M);
+        Gate mk[9];  // gates of the view hidden, h7, h6, ..., h0
 #pragma unroll
-        for (int l = 0; l < 9; ++l) mk[l] = *reinterpret_cast<const uint4*>(a.masks + ((int64_t)(8 - l) * Mp + blk * 32 + c) * 8 + 4 * hh);
-        // ---- colour head: d hv = gate * (Wc^T d rgb)
+        for (int l = 0; l < 9; ++l) mk[l] = load_gate(a.masks, 8 - l, Mp, T.blk * TILE + T.c, T.g);
+        // ---- colour head: d hv = gate * (Wc^T d rgb); the k-step holds KSTEP features, 3 real (lane group 0)
         BFrag<NP> b1[1];
         {
             float x[8];
-            float* dt = a.drgb_t + blk * (32 * 32) + lo;
+            float* dt = a.drgb_t + T.blk * (32 * TILE) + T.lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int f0 = 8 * (j >> 2) + (j & 3);  // feature f0 + 4 hh of the 16 this k-step holds
-                x[j] = (live && hh == 0 && f0 < 3) ? a.d_rgb[rc * 3 + (f0 < 3 ? f0 : 0)] : 0.f;
-                dt[f0 * 32] = x[j];
+                const int f = QB * (j >> 2) + 4 * T.g + (j & 3);
+                x[j] = (T.live && f < 3) ? a.d_rgb[T.rc * 3 + (f < 3 ? f : 0)] : 0.f;
+                dt[(QB * (j >> 2) + (j & 3)) * TILE] = x[j];
             }
             split_into<NP>(x, b1[0]);
         }
-        BFrag<NP> bc[8];
+        BFrag<NP> bc[KS_C];
         {
-            f32x16 av[4];
-            chain_gemm<NP, 1, 4, false, true>(R, b1, av, lane);
-            const uint4 m8 = pop_front(mk);
-            const uint32_t w[4] = {m8.x, m8.y, m8.z, m8.w};
-            gate_bits<4>(av, w);
-            float* ht = a.dhv_t + blk * (128 * 32) + lo;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                store_tile(ht, t, av[t]);
-                acc_to_b<NP>(av[t], bc[2 * t], bc[2 * t + 1]);
-            }
+            accv av[NT_C];
+            chain_gemm<NP, 1, NT_C, false, true>(R, b1, av, lane);
+            gate_bits<NT_C>(av, pop_front(mk));
+            store_t<NT_C>(a.dhv_t + T.blk * (128 * TILE) + T.lo, av);
+            acc_to_b<NP, NT_C, KS_C>(av, bc);
         }
         // ---- view layer: d bottleneck = Wv[:, :256]^T d hv ; then [d bottleneck | d raw_density] through [We ; Wd]^T
-        BFrag<NP> be[17];
-        f32x16 acc[8];
+        BFrag<NP> be[KS_H + 1];
+        accv acc[NT_H];
         {
-            chain_gemm<NP, 8, 8, false, true>(R, bc, acc, lane);
-            float* bt = a.d8_t + blk * (288 * 32) + lo;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                store_tile(bt, t, acc[t]);
-                acc_to_b<NP>(acc[t], be[2 * t], be[2 * t + 1]);
-            }
-            const float z = a.raw_den[rc * a.nc] + a.density_bias;
-            const float add0 = (a.sdot && live) ? ch_sp_d2(z) * a.sdot[rc] : 0.f;
+            chain_gemm<NP, KS_C, NT_H, false, true>(R, bc, acc, lane);
+            float* bt = a.d8_t + T.blk * (288 * TILE) + T.lo;
+            store_t<NT_H>(bt, acc);
+            acc_to_b<NP, NT_H, KS_H + 1>(acc, be);
+            const float z = a.raw_den[T.rc * a.nc] + a.density_bias;
+            const float add0 = (a.sdot && T.live) ? ch_sp_d2(z) * a.sdot[T.rc] : 0.f;
             float x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int f0 = 8 * (j >> 2) + (j & 3);
-                const int ch = f0 + 4 * hh;
+                const int ch = QB * (j >> 2) + 4 * T.g + (j & 3);
                 float v = 0.f;
-                if (live && ch < a.nc) v = a.d_den[rc * a.nc + ch] + (ch == 0 ? add0 : 0.f);
+                if (T.live && ch < a.nc) v = a.d_den[T.rc * a.nc + ch] + (ch == 0 ? add0 : 0.f);
                 x[j] = v;
-                bt[(256 + f0) * 32] = v;
+                bt[(256 + QB * (j >> 2) + (j & 3)) * TILE] = v;
             }
-            split_into<NP>(x, be[16]);
+            split_into<NP>(x, be[KS_H]);
             if (a.coef_t) {
-                float* ct = a.coef_t + blk * (32 * 32) + lo;
-                const float cf = live ? ch_sp_d1(z) : 0.f;
+                float* ct = a.coef_t + T.blk * (32 * TILE) + T.lo;
+                const float cf = T.live ? ch_sp_d1(z) : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int f0 = 8 * (j >> 2) + (j & 3);
-                    ct[f0 * 32] = (f0 == 0 && hh == 0) ? cf : 0.f;
+                    const int f = QB * (j >> 2) + 4 * T.g + (j & 3);
+                    ct[(QB * (j >> 2) + (j & 3)) * TILE] = f == 0 ? cf : 0.f;
                 }
             }
         }
-        BFrag<NP> bh[16];
-        chain_gemm<NP, 17, 8, false, true>(R, be, acc, lane);
-        finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)7 * Mp * 256 + blk * (256 * 32) + lo, bh);
+        BFrag<NP> bh[KS_H];
+        chain_gemm<NP, KS_H + 1, NT_H, false, true>(R, be, acc, lane);
+        finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
-            chain_gemm<NP, 16, 8, false, true>(R, bh, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)(l - 1) * Mp * 256 + blk * (256 * 32) + lo, bh);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+            finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
         }
         if (a.d_mean) {  // uniform: d enc over [delta_0 | delta_5], then the encoding's adjoint
             float mu[3], cv[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                mu[i] = a.mean[rc * 3 + i];
-                cv[i] = a.cov[rc * 3 + i];
+                mu[i] = a.mean[T.rc * 3 + i];
+                cv[i] = a.cov[T.rc * 3 + i];
             }
-            f32x16 a3[3];
-            chain_gemm<NP, 16, 3, false, true>(R, bh, a3, lane);
-            reload_b<NP>(a.delta_t + (int64_t)5 * Mp * 256 + blk * (256 * 32) + lo, hh, bh);
-            chain_gemm<NP, 16, 3, false, false>(R, bh, a3, lane);
+            accv a3[NT_ENC];
+            chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane);
+            reload_b<NP, KS_H>(a.delta_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane);
             float dm[3];
-            ipe_backward_tiles(a3, mu, cv, hh, dm);
-            if (live && hh == 0) {
-                a.d_mean[row * 3] = dm[0];
-                a.d_mean[row * 3 + 1] = dm[1];
-                a.d_mean[row * 3 + 2] = dm[2];
+            ipe_backward_tiles(a3, mu, cv, T.g, dm);
+            if (T.live && T.g == 0) {
+                a.d_mean[T.row * 3] = dm[0];
+                a.d_mean[T.row * 3 + 1] = dm[1];
+                a.d_mean[T.row * 3 + 2] = dm[2];
             }
         }
     }
     R.drain();
 }
 
-
 // ------------------------------------------------------------------------------------- weight gradients (TN GEMM)
-// dW[N1 x N2] (+)= sum over samples X[s][i] * Y[s][j] with X, Y in the T32 layout (sample-minor), on the bf16 matrix
+// dW[N1 x N2] (+)= sum over samples X[s][i] * Y[s][j] with X, Y in the T layout (sample-minor), on the bf16 matrix
 // cores: A = X^T (k = sample), B = Y.  A workgroup owns the whole [TMW x TNW] result for a contiguous range of
 // 16-sample half blocks (split over samples; per-workgroup slabs are reduced afterwards).  Staging: fp32 from HBM to
 // registers (full 64-B half rows, coalesced), split ONCE per element into NP bf16 planes, 8-B LDS writes into
@@ -1022,6 +1039,20 @@ struct WgArgs {
     int bias;
 };
 
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<NP>& b, f32x16 v) {
+    if constexpr (NP == 3) {  // small terms first
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
+    } else {
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
+    }
+    return v;
+}
 template <int NP, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NTH = 64 * WM * WN, TMW = 32 * TM * WM, TNW = 32 * TN * WN;
@@ -1063,19 +1094,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             }
         const WSeg& S = a.seg[sg];
         bw[set] = S.bias ? 1.f : 0.f;
-        const int64_t blk = hb >> 1;
-        const int half = (int)(hb & 1);
-        const float* xb = S.X + blk * ((int64_t)S.FX * 32) + half * 16;
-        const float* yb = S.Y + blk * ((int64_t)S.FY * 32) + half * 16;
+        const int64_t blk = hb / (TILE / 16);  // a T-layout sample block holds TILE / 16 half blocks
+        const int half = (int)(hb % (TILE / 16));
+        const float* xb = S.X + blk * ((int64_t)S.FX * TILE) + half * 16;
+        const float* yb = S.Y + blk * ((int64_t)S.FY * TILE) + half * 16;
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
-            if (CX % NTH == 0 || idx < CX) xr[set][i] = *reinterpret_cast<const f32x4*>(xb + (idx >> 2) * 32 + (idx & 3) * 4);
+            if (CX % NTH == 0 || idx < CX) xr[set][i] = *reinterpret_cast<const f32x4*>(xb + (idx >> 2) * TILE + (idx & 3) * 4);
         }
 #pragma unroll
         for (int i = 0; i < LY; ++i) {
             const int idx = tid + NTH * i;
-            if (CY % NTH == 0 || idx < CY) yr[set][i] = *reinterpret_cast<const f32x4*>(yb + (idx >> 2) * 32 + (idx & 3) * 4);
+            if (CY % NTH == 0 || idx < CY) yr[set][i] = *reinterpret_cast<const f32x4*>(yb + (idx >> 2) * TILE + (idx & 3) * 4);
         }
     };
     auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v) {
@@ -1135,7 +1166,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) bf.p[p] = frag(ys + p * PY, 32 * (wn * TN + j) + fr);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split<NP>(af[i], bf, acc[i][j]);
+            for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split32<NP>(af[i], bf, acc[i][j]);
         }
     };
     if (h0 < h1) {
@@ -1177,8 +1208,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------- host side
-static void fill_layer(PackLayer& L, int chunk0, int KS, int NT, int CKS, int rows_valid) {
-    L.chunk0 = chunk0; L.KS = KS; L.NT = NT; L.CKS = CKS; L.rows_valid = rows_valid;
+static void fill_layer(PackLayer& L, int chunk0, int KS, int NT, int rows_valid) {
+    L.chunk0 = chunk0; L.KS = KS; L.NT = NT; L.rows_valid = rows_valid;
     L.nseg = 0; L.aux_off = -1; L.aux_n = 0;
 }
 static void add_seg(PackLayer& L, int64_t off, int ld, int k0, int kvalid, int transposed, int col0) {
@@ -1190,13 +1221,19 @@ static PackTable fwd_table(int nc) {
     const PnLayout P = pn_layout(nc);
     PackTable T;
     T.n = F_COUNT;
+    const int ld5 = PN_WIDTH + PN_ENC_DIM;
     for (int i = 0; i < F_COUNT; ++i) {
         PackLayer& L = T.L[i];
         const int KS = fwd_ks(i), NT = fwd_nt(i);
-        fill_layer(L, fwd_chunk0<NP>(i), KS, NT, cks_of<NP>(KS, NT), 32 * NT);
-        if (i <= F_L7) {
-            const int l = i;
-            const int k = (l == 0) ? PN_ENC_DIM : (l == 5 ? PN_WIDTH + PN_ENC_DIM : PN_WIDTH);
+        fill_layer(L, fwd_chunk0<NP>(i), KS, NT, TILE * NT);
+        if (i == F_L5) {  // hidden columns of layer 5 (+ its bias); the skip columns follow as F_L5E
+            add_seg(L, P.w[5], ld5, 0, PN_WIDTH, 0, 0);
+            L.aux_off = P.b[5]; L.aux_n = PN_WIDTH;
+        } else if (i == F_L5E) {
+            add_seg(L, P.w[5], ld5, 0, PN_ENC_DIM, 0, PN_WIDTH);
+        } else if (i <= F_L7) {
+            const int l = i < F_L5E ? i : i - 1;
+            const int k = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
             add_seg(L, P.w[l], k, 0, k, 0, 0);
             L.aux_off = P.b[l]; L.aux_n = PN_WIDTH;
         } else if (i == F_DEN) {
@@ -1207,6 +1244,7 @@ static PackTable fwd_table(int nc) {
             add_seg(L, P.we, PN_WIDTH, 0, PN_WIDTH, 0, 0);
             L.aux_off = P.be; L.aux_n = PN_WIDTH;
         } else if (i == F_VIEW) {
+            L.rows_valid = PN_WIDTH_COND;
             add_seg(L, P.wv, PN_WIDTH + PN_VIEW_DIM, 0, PN_WIDTH + PN_VIEW_DIM, 0, 0);
             L.aux_off = P.bv; L.aux_n = PN_WIDTH_COND;
         } else {  // F_COLOR
@@ -1228,8 +1266,9 @@ static PackTable bwd_table(int nc) {
     for (int i = 0; i < B_COUNT; ++i) {
         PackLayer& L = T.L[i];
         const int KS = bwd_ks(i), NT = bwd_nt(i);
-        fill_layer(L, bwd_chunk0<NP>(i), KS, NT, cks_of<NP>(KS, NT), 32 * NT);
+        fill_layer(L, bwd_chunk0<NP>(i), KS, NT, TILE * NT);
         if (i == B_COLOR) {  // A[i = hv feature][k = rgb channel] = Wc[k][i]
+            L.rows_valid = PN_WIDTH_COND;
             add_seg(L, P.wc, PN_WIDTH_COND, 0, 3, 1, 0);
         } else if (i == B_VIEW) {  // A[i = bottleneck feature][k = hv feature] = Wv[k][i]
             add_seg(L, P.wv, ldv, 0, PN_WIDTH_COND, 1, 0);
@@ -1239,10 +1278,12 @@ static PackTable bwd_table(int nc) {
         } else if (i >= B_L7 && i <= B_L1) {  // A[i = input feature][k = output feature] = W_l[k][i]
             const int l = 7 - (i - B_L7);
             add_seg(L, P.w[l], l == 5 ? ld5 : PN_WIDTH, 0, PN_WIDTH, 1, 0);
-        } else {  // B_DENC: k < 256: W0[k][i] ; k >= 256: W5[k - 256][256 + i]
+        } else if (i == B_DENC0) {  // A[i = enc feature][k] = W0[k][i]
             L.rows_valid = PN_ENC_DIM;
             add_seg(L, P.w[0], PN_ENC_DIM, 0, PN_WIDTH, 1, 0);
-            add_seg(L, P.w[5], ld5, PN_WIDTH, PN_WIDTH, 1, PN_WIDTH);
+        } else {  // B_DENC1: W5[k][256 + i]
+            L.rows_valid = PN_ENC_DIM;
+            add_seg(L, P.w[5], ld5, 0, PN_WIDTH, 1, PN_WIDTH);
         }
     }
     T.nchunks = bwd_chunk0<NP>(B_COUNT);
@@ -1267,6 +1308,7 @@ template <typename K, typename A>
 static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s, int cls, double flops);
 
 static int g_chain_cus = 0;
+static int chain_cus();
 static int chain_grid(int64_t nst) {
     if (!g_chain_cus) {
         int dev = 0;
@@ -1274,7 +1316,12 @@ static int chain_grid(int64_t nst) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) g_chain_cus = 256;
         else g_chain_cus = pr.multiProcessorCount;
     }
-    return (int)(nst < g_chain_cus ? nst : g_chain_cus);
+    const int64_t wgs = (int64_t)g_chain_cus * CH_WG_PER_CU;
+    return (int)(nst < wgs ? nst : wgs);
+}
+static int chain_cus() {
+    chain_grid(1);
+    return g_chain_cus;
 }
 
 template <typename K, typename A>
@@ -1325,7 +1372,7 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     a.half_total = total;
     const int TMW = kCfgM[j.cfg], TNW = kCfgN[j.cfg];
     const int64_t stride = (int64_t)TMW * TNW + TMW;
-    int cus = chain_grid(1 << 30);
+    int cus = chain_cus();
     int64_t nsplit = cus;
     if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;  // at least four half blocks per workgroup
     if (nsplit < 1) nsplit = 1;
@@ -1358,6 +1405,9 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
 
 extern "C" {
 
+/* samples per T-layout block (= samples per wave of the chain kernels): 16 or 32 */
+int pn_chain_tile(void) { return TILE; }
+
 // bytes of the packed chains for `planes` (3: exact split, 1: plain bf16): [forward chain | backward chain]
 int64_t pn_chain_pack_bytes(int planes) {
     if (planes == 3) return (int64_t)(fwd_chunk0<3>(F_COUNT) + bwd_chunk0<3>(B_COUNT)) * Cfg<3>::SLOT;
@@ -1385,7 +1435,7 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     if (!pack || !mean || !cov || !viewdirs || !enc_t || !acts_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;
     FwdArgs a{};
     a.M = M;
-    a.nst = pn_pad(M) / 128;
+    a.nst = pn_pad(M) / CH_SAMPLES;
     a.rows_per_ray = rows_per_ray;
     a.nc = nc;
     a.view_rows = view_rows;
@@ -1406,7 +1456,7 @@ int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, con
     if (!params || !pack || !mean || !cov || !masks || !raw_den || !rs_t || !grad_mean) return PN_ERR_NULL;
     SweepArgs a{};
     a.M = M;
-    a.nst = pn_pad(M) / 128;
+    a.nst = pn_pad(M) / CH_SAMPLES;
     a.nc = nc;
     a.density_bias = density_bias;
     const int64_t slot = planes == 3 ? Cfg<3>::SLOT : Cfg<1>::SLOT;
@@ -1431,7 +1481,7 @@ int pn_chain_tangent(int64_t M, int nc, int planes, const float* params, const v
     if (!params || !pack || !mean || !cov || !masks || !v || !edot_t || !tang_t || !sdot) return PN_ERR_NULL;
     SweepArgs a{};
     a.M = M;
-    a.nst = pn_pad(M) / 128;
+    a.nst = pn_pad(M) / CH_SAMPLES;
     a.nc = nc;
     a.pack = (const unsigned char*)pack;
     a.nchunk = planes == 3 ? fwd_chunk0<3>(F_DEN) : fwd_chunk0<1>(F_DEN);
@@ -1454,14 +1504,14 @@ int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const v
     if ((sdot == nullptr) != (coef_t == nullptr)) return PN_ERR_NULL;
     BwdArgs a{};
     a.M = M;
-    a.nst = pn_pad(M) / 128;
+    a.nst = pn_pad(M) / CH_SAMPLES;
     a.nc = nc;
     a.density_bias = density_bias;
     const int64_t slot = planes == 3 ? Cfg<3>::SLOT : Cfg<1>::SLOT;
     const int f_all = planes == 3 ? fwd_chunk0<3>(F_COUNT) : fwd_chunk0<1>(F_COUNT);
     a.pack = (const unsigned char*)pack + (int64_t)f_all * slot;
     a.nchunk = d_mean ? (planes == 3 ? bwd_chunk0<3>(B_COUNT) : bwd_chunk0<1>(B_COUNT))
-                      : (planes == 3 ? bwd_chunk0<3>(B_DENC) : bwd_chunk0<1>(B_DENC));
+                      : (planes == 3 ? bwd_chunk0<3>(B_DENC0) : bwd_chunk0<1>(B_DENC0));
     a.masks = masks; a.raw_den = raw_den; a.d_rgb = d_raw_rgb; a.d_den = d_raw_den; a.sdot = sdot;
     a.mean = mean; a.cov = cov;
     a.drgb_t = drgb_t; a.dhv_t = dhv_t; a.d8_t = d8_t; a.delta_t = delta_t; a.coef_t = coef_t; a.d_mean = d_mean;
@@ -1538,7 +1588,7 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     }
     {  // density head: d raw_density^T h7 (+ softplus' rows against hdot_7 into row 0)
         WgJob j{};
-        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t + 256 * 32, act(e, 7), mp(e) / 16, 288, 256, 1};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t + 256 * TILE, act(e, 7), mp(e) / 16, 288, 256, 1};
         j.cfg = 3; j.rows = nc; j.cols = 256; j.dst = grads + L.wd; j.ldd = 256; j.dbias = grads + L.bd;
         if ((rc = run(j)) != PN_OK) return rc;
         WgJob k{};

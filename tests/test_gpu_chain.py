@@ -24,7 +24,9 @@ def st():
 
 
 def t32_rows(t, Mp, F):
-    return t.reshape(Mp // 32, F, 32).permute(0, 2, 1).reshape(Mp, F)
+    from pano_nerf_amd import _lib
+    tile = int(_lib.load().pn_chain_tile())
+    return t.reshape(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
 
 
 class Ev:

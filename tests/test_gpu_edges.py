@@ -45,7 +45,7 @@ def test_ragged_and_tiny_batches_match_oracle(B, N):
     assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
     ref_g = torch.autograd.grad(ref_loss, list(p.values()))
     check_flat_grad_per_tensor(g.detach().cpu().numpy(), {k: x.detach().numpy() for k, x in zip(p.keys(), ref_g)}, 5,
-                               second_order=True)
+                               second_order=True, n_rows=B * (2 * N + 100))
 
 
 def test_maximum_sample_count():
@@ -159,4 +159,5 @@ def test_assorted_configurations_match_oracle(cfg):
     assert bool(torch.isfinite(g).all())
     check_flat_grad_per_tensor(g.detach().cpu().numpy(),
                                {k: (None if x is None else x.detach().numpy()) for k, x in zip(p.keys(), ref_g)},
-                               5 if kind == "pano" else 1, second_order=bool(ort) or kind == "pano")
+                               5 if kind == "pano" else 1, second_order=bool(ort) or kind == "pano",
+                               n_rows=B * (2 * N + (100 if (kind == "pano" and surf) else 0)))

@@ -58,10 +58,12 @@ def check_tuple(outs, g, prefix, names, g64=None):
                     med = float(np.median(rel))
                     assert med < 1e-4, (key, med)
                     # >= 99 % of the elements within 1e-3.  The goldens hold 16 / 64 rays, where 1 % is less
-                    # than one ray: two rays (6 elements) may sit on a flipped ReLU gate (0-3 gates flip per run under ANY
-                    # fp32 summation order; one ray does in the reference's own fp32-vs-fp64 comparison on these batches)
+                    # than one ray: three rays (9 elements) may sit on a flipped ReLU gate (0-3 gates flip per run under ANY
+                    # fp32 summation order; one ray does in the reference's own fp32-vs-fp64 comparison on these batches).
+                    # The pointwise statement is tests/test_gpu_grads.py::test_gate_consistent_*: with the kernels' gate
+                    # decisions forced into the oracle, every output agrees to 1e-4
                     bad = int(np.sum(np.abs(got - g[key]) > 1e-3 * max(float(np.max(np.abs(g[key]))), 1e-12)))
-                    assert bad <= max(6, int(0.01 * got.size)), (key, bad, got.size)
+                    assert bad <= max(9, int(0.01 * got.size)), (key, bad, got.size)
                 k64 = f"val64/l1/{nme}"
                 if g64 is not None and k64 in g64 and prefix == "val" and got.ndim > 0:
                     # vs the reference's own fp64 run: a ReLU gate whose pre-activation is ~1e-7 can flip under
@@ -69,7 +71,7 @@ def check_tuple(outs, g, prefix, names, g64=None):
                     # gate is on the per-ray error with the worst 5 % of rays (at least one) set aside
                     ours = np.sort(np.abs(got - g64[k64]).reshape(got.shape[0], -1).max(-1))
                     theirs = np.sort(np.abs(g[key] - g64[k64]).reshape(got.shape[0], -1).max(-1))
-                    drop = max(2, int(np.ceil(0.05 * got.shape[0])))  # rays allowed to sit on a flipped gate
+                    drop = max(3, int(np.ceil(0.05 * got.shape[0])))  # rays allowed to sit on a flipped gate
                     assert ours[-drop - 1] <= 2 * theirs[-drop - 1] + 1e-5, (key, ours[-3:], theirs[-3:])
             else:
                 assert e < 1e-4, (key, e)

@@ -191,10 +191,14 @@ def gates_of(ev, fused):
     M = ev.M
     words = ev.masks[:, :M].to(torch.int64) & 0xffffffff  # [9, M, 8]
     f = torch.arange(256, device=words.device)
-    if fused:  # [M][2 halves][4 words]: word t >> 1 of half hh, bit 16 (t & 1) + e (pn_chain.hip)
-        t, col = f >> 5, f & 31
-        hh, e = (col >> 2) & 1, (col & 3) + 4 * (col >> 3)
-        w, bit = hh * 4 + (t >> 1), 16 * (t & 1) + e
+    if fused:  # pn_chain.hip: lane group g = (f % QB) / 4 holds bit 4 (f / QB) + f % 4 of its 8 / NG words, QB = 4 NG, NG = 64 / tile
+        from pano_nerf_amd import _lib
+        tile = int(_lib.load().pn_chain_tile())
+        ng = 64 // tile
+        qb_size = 4 * ng
+        qb, g, i = f // qb_size, (f % qb_size) // 4, f % 4
+        bitpos = 4 * qb + i
+        w, bit = g * (8 // ng) + (bitpos >> 5), bitpos & 31
     else:      # word col / 32, bit c * 8 + i for column 32 (col / 32) + 4 i + c (pn_common.h)
         w, bit = f >> 5, (f & 3) * 8 + ((f & 31) >> 2)
     return ((words[:, :, w] >> bit) & 1).bool().cpu()
@@ -204,8 +208,9 @@ def gates_of(ev, fused):
 @pytest.mark.parametrize("case", CASES)
 def test_gate_consistent_gradients_pointwise(golden, case, mode):
     """The strong form of gradient parity: the oracle is run with the ReLU gate decisions the GPU kernels took (read back
-    from their bit masks), which removes the one ill-conditioned ingredient — and then EVERY entry of EVERY gradient
-    tensor, first- and second-order alike, must agree to 1e-4 of the tensor max (measured: ~1e-5)."""
+    from their bit masks), which removes the one ill-conditioned ingredient — and then EVERY output (normal, surface_rgb,
+    shading, ort_loss included) and EVERY entry of EVERY gradient tensor, first- and second-order alike, must agree to 1e-4
+    of the tensor max (measured: ~1e-5 .. 5e-5)."""
     import pano_nerf_amd as pn
     g, s = golden("pano_full_" + case), golden("stages_" + case)
     N = s["t_det"].shape[1] - 1
@@ -231,6 +236,15 @@ def test_gate_consistent_gradients_pointwise(golden, case, mode):
         ref_loss = orc.pano_loss(ref, rays_c.lossmult, rgbs)
         ref_g = torch.autograd.grad(ref_loss, list(p.values()))
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    # every OUTPUT too, the normal-derived ones included: pointwise 1e-4 of the tensor scale
+    names = ("comp_rgb", "distance", "ort_loss", "normal", "albedo", "roughness", "surface_rgb", "diffuse", "shading")
+    for lvl in (0, 1):
+        for nme, got_o, ref_o in zip(names, outs[lvl], ref[lvl]):
+            assert (got_o is None) == (ref_o is None), (lvl, nme)
+            if got_o is not None:
+                a_, b_ = got_o.detach().cpu().numpy().astype(np.float64), ref_o.detach().numpy().astype(np.float64)
+                e_ = float(np.abs(a_ - b_).max()) / max(float(np.abs(b_).max()), 1e-30)
+                assert e_ <= 1e-4, (f"l{lvl}/{nme}", e_)
     by_name = {k: x.detach().numpy().astype(np.float64).reshape(-1) for k, x in zip(p.keys(), ref_g)}
     worst = 0.0
     for k, lo, hi in tensors(5):

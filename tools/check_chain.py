@@ -11,7 +11,8 @@ E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
 
 
 def t32_to_rows(t, Mp, F):
-    return t.view(Mp // 32, F, 32).permute(0, 2, 1).reshape(Mp, F)
+    tile = int(lib.pn_chain_tile())
+    return t.view(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
 
 
 def run(M, rows_per_ray, planes, nc=5, reps=0):
@@ -63,17 +64,16 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     hv = t32_to_rows(acts_t[8 * Mp * 256 + Mp * 288:], Mp, 128)[:M]
     print("  hv       ", rel(hv, acts[9, :M, :128]))
     print("  raw_rgb  ", rel(rr2, rr), " raw_den", rel(rd2, rd))
-    # gate bits: word w of half hh covers tiles 2w, 2w+1, bit 16 (t & 1) + e <-> feature 32 t + (e & 3) + 8 (e >> 2) + 4 hh
-    mf = masks_f.view(9, Mp, 2, 4)
+    # gate bits (pn_chain.hip): lane group g = (f % QB) / 4 holds bit 4 (f / QB) + f % 4 of its 8 / NG words
+    tile = int(lib.pn_chain_tile()); ng = 64 // tile; qbs = 4 * ng
     bad = 0
     for l in (0, 5, 7):
         h = t32_to_rows(acts_t[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
-        for hh in range(2):
-            for t in (0, 3, 7):
-                for e in (0, 5, 15):
-                    f = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh
-                    bit = (mf[l, :M, hh, t >> 1] >> (16 * (t & 1) + e)) & 1
-                    bad += int((bit.bool() != (h[:, f] > 0)).sum())
+        for f in (0, 5, 37, 100, 131, 255):
+            qb, g, i = f // qbs, (f % qbs) // 4, f % 4
+            word = masks_f[l, :M, g * (8 // ng) + ((4 * qb + i) >> 5)].to(torch.int64) & 0xffffffff
+            bit = (word >> ((4 * qb + i) & 31)) & 1
+            bad += int((bit.bool() != (h[:, f] > 0)).sum())
     print("  gate-bit mismatches (sampled):", bad)
     if reps:
         torch.cuda.synchronize()

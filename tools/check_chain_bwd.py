@@ -12,7 +12,8 @@ Z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
 
 
 def t32_to_rows(t, Mp, F):
-    return t.reshape(Mp // 32, F, 32).permute(0, 2, 1).reshape(Mp, F)
+    tile = int(lib.pn_chain_tile())
+    return t.reshape(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
 
 
 def rel(a, b):
