@@ -494,6 +494,54 @@ __device__ __forceinline__ float ch_sp_d2(float x) {
 }
 __device__ __forceinline__ float sel3(const float (&v)[3], int ch) { return ch == 0 ? v[0] : (ch == 1 ? v[1] : v[2]); }
 
+// sin / cos of an fp32 argument as large as 2^20 (the encoding's 2^15 * mean), absolute error < 2e-7, in ~25 VALU
+// instructions and without the divergent Payne-Hanek path of the library sinf (the encoding was 12 % + 9 % of a wave's
+// forward tile): y / 2pi as an exact double-float product (fma error term + the low part of 1 / 2pi), the integer part
+// removed exactly, the quarter turn folded, then Taylor kernels on [-pi/4, pi/4] (tools/check_fast_sincos.py validates the
+// scheme in numpy: max error 1.9e-7 over 2^-5 <= |y| < 2^19).  `y` is the ALREADY ROUNDED fp32 argument: the reference's
+// cosine is sin(fl32(y + pi/2)) (models/mip.py:428,437), which the callers reproduce by passing that rounded sum.
+__device__ __forceinline__ float red_turns(float y, int& quadrant) {
+    const float c_hi = 0.15915494f;    // fl32(1 / 2pi)
+    const float c_lo = 6.4206382e-9f;  // 1 / 2pi - c_hi
+    const float p = y * c_hi;
+    float e = __builtin_fmaf(y, c_hi, -p);
+    e = __builtin_fmaf(y, c_lo, e);
+    const float f = (p - __builtin_rintf(p)) + e;  // fraction of a turn in [-0.5, 0.5] (+ a hair)
+    const float q4 = f * 4.0f;
+    const float qn = __builtin_rintf(q4);          // nearest quarter turn
+    quadrant = (int)qn;
+    return (q4 - qn) * 1.5707963267948966f;        // remainder in [-pi/4, pi/4]
+}
+__device__ __forceinline__ float ksin(float x) {
+    const float z = x * x;
+    float p = __builtin_fmaf(z, 2.7557319e-6f, -1.9841270e-4f);
+    p = __builtin_fmaf(z, p, 8.3333333e-3f);
+    p = __builtin_fmaf(z, p, -1.6666667e-1f);
+    return __builtin_fmaf(x * z, p, x);
+}
+__device__ __forceinline__ float kcos(float x) {
+    const float z = x * x;
+    float p = __builtin_fmaf(z, -2.7557319e-7f, 2.4801587e-5f);
+    p = __builtin_fmaf(z, p, -1.3888889e-3f);
+    p = __builtin_fmaf(z, p, 4.1666667e-2f);
+    p = __builtin_fmaf(z, p, -0.5f);
+    return __builtin_fmaf(z, p, 1.0f);
+}
+__device__ __forceinline__ float fast_sin(float y) {
+    int q;
+    const float r = red_turns(y, q);
+    const float sv = ksin(r), cv = kcos(r);
+    const float v = (q & 1) ? cv : sv;
+    return (q & 2) ? -v : v;
+}
+__device__ __forceinline__ float fast_cos(float y) {
+    int q;
+    const float r = red_turns(y, q);
+    const float sv = ksin(r), cv = kcos(r);
+    const float v = (q & 1) ? sv : cv;
+    return ((q + 1) & 2) ? -v : v;
+}
+
 // per-lane coordinates of a wave's tile
 struct Tile {
     int64_t blk, row, rc;  // sample block, sample row, row clamped into [0, M)
@@ -527,14 +575,14 @@ __device__ __forceinline__ void encode(const float (&mu)[3], const float (&cv)[3
             const int l = f / 3, ch = f - 3 * l;
             const float sc = (float)(1 << l);
             const float y = sel3(mu, ch) * sc;
-            const float e0 = expf(-0.5f * (sel3(cv, ch) * (sc * sc)));
+            const float e0 = __expf(-0.5f * (sel3(cv, ch) * (sc * sc)));
             if constexpr (MODE == 0) {
-                x[qb][i] = e0 * sinf(y);
-                x[qb + NQ / 2][i] = e0 * sinf(y + HALF_PI_F);
+                x[qb][i] = e0 * fast_sin(y);
+                x[qb + NQ / 2][i] = e0 * fast_sin(y + HALF_PI_F);
             } else {
                 const float e = e0 * sc * sel3(vv, ch);
-                x[qb][i] = e * cosf(y);
-                x[qb + NQ / 2][i] = e * cosf(y + HALF_PI_F);
+                x[qb][i] = e * fast_cos(y);
+                x[qb + NQ / 2][i] = e * fast_cos(y + HALF_PI_F);
             }
         }
 #pragma unroll
@@ -574,8 +622,8 @@ __device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], co
             const int l = f / 3, ch = f - 3 * l;
             const float sc = (float)(1 << l);
             const float y = sel3(mu, ch) * sc;
-            const float ex = expf(-0.5f * (sel3(cv, ch) * (sc * sc))) * sc;
-            const float d = AQ(acc, qb, i) * ex * cosf(cosine ? y + HALF_PI_F : y);
+            const float ex = __expf(-0.5f * (sel3(cv, ch) * (sc * sc))) * sc;
+            const float d = AQ(acc, qb, i) * ex * fast_cos(cosine ? y + HALF_PI_F : y);
             dm[0] += ch == 0 ? d : 0.f;
             dm[1] += ch == 1 ? d : 0.f;
             dm[2] += ch == 2 ? d : 0.f;
@@ -711,7 +759,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
                     } else if (v < PN_VIEW_DIM) {
                         const int i = v - 3, f = i % 12, half = i / 12, l = f / 3, ch = f % 3;
                         const float xb = sel3(vd, ch) * (float)(1 << l);
-                        o = sinf(half ? xb + HALF_PI_F : xb);
+                        o = fast_sin(half ? xb + HALF_PI_F : xb);
                     }
                     x[j] = o;
                     bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = o;
