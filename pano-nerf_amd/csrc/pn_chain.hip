@@ -69,7 +69,8 @@ constexpr int KS_C = 128 / KSTEP, NT_C = 128 / TILE;      // the 128-wide view h
 
 template <int NP>
 struct Cfg {
-    static constexpr int CF = NP == 3 ? 24 : 32;       // fragments (1 KB each) per chunk
+    // fragments (1 KB each) per chunk; with two workgroups per CU a ring of three slots must stay under 80 KB
+    static constexpr int CF = NP == 3 ? 24 : (CH_WG_PER_CU == 2 ? 16 : 32);
     static constexpr int PER = CF / NP;                // GEMM steps (one A fragment set each) per chunk
     static constexpr int SLOT = (CF + 1) * 1024;       // + 1 KB of aux floats (bias) per chunk
     static constexpr int NSLOT = CH_WG_PER_CU == 2 ? 3 : (NP == 3 ? 5 : 4);  // ring slots

@@ -16,6 +16,7 @@
 // lanes 32-63: k = 8j+4..8j+7) and feeds them to four consecutive MFMAs.
 #include "pn_common.h"
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 
 // ---------------------------------------------------------------------------- launch timing
@@ -37,6 +38,8 @@ static int g_dbg = 0;
 #define PN_DBG 0
 #define PN_ABL(x) 0
 #endif
+// (autograd runs the backward of different devices on different host threads: the bookkeeping below is locked)
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_free_events;
 #define PN_PROF_CLASSES 12
@@ -58,7 +61,9 @@ struct ProfScope {
     hipStream_t s;
     bool live;
     ProfScope(int cls, double flops, hipStream_t s_) : s(s_), live(false) {
-        if (!g_prof_on || g_prof.size() > (1u << 20)) return;
+        if (!g_prof_on) return;
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (g_prof.size() > (1u << 20)) return;
         r.cls = cls;
         r.flops = flops;
         r.e0 = prof_event();
@@ -67,13 +72,16 @@ struct ProfScope {
         live = hipEventRecord(r.e0, s) == hipSuccess;
     }
     ~ProfScope() {
-        if (live && hipEventRecord(r.e1, s) == hipSuccess) g_prof.push_back(r);
+        if (!live) return;
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (hipEventRecord(r.e1, s) == hipSuccess) g_prof.push_back(r);
     }
 };
 // the same bracket for the kernels of other translation units (pn_chain.hip)
 PnProfScope::PnProfScope(int cls, double flops, hipStream_t s) : impl(new ProfScope(cls, flops, s)) {}
 PnProfScope::~PnProfScope() { delete static_cast<ProfScope*>(impl); }
 static void prof_drain() {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {

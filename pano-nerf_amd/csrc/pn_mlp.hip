@@ -15,6 +15,7 @@
 // balance), see DESIGN.md.
 #include "pn_common.h"
 #include <math.h>
+#include <mutex>
 #include <vector>
 
 #define ST(s) ((hipStream_t)(s))
@@ -633,9 +634,11 @@ int pn_density_grad(int64_t M, int nc, float density_bias, const float* params, 
 // events for the fork/join between the data-gradient chain (main stream) and the weight-gradient work (side
 // stream); a small process-wide pool, re-recorded every call (graph-capturable fork/join pattern)
 static std::vector<hipEvent_t> g_events;
+static std::mutex g_events_mu;
 struct EventRing {
     size_t next = 0;
     hipEvent_t get() {
+        std::lock_guard<std::mutex> lock(g_events_mu);
         if (next == g_events.size()) {
             hipEvent_t e;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
