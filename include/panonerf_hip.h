@@ -183,16 +183,19 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_dens
 int pn_chain_tile(void);
 int64_t pn_chain_pack_bytes(int planes);
 int pn_chain_pack(const float* params, int num_density_channels, int planes, void* pack, void* stream);
-/* floats of acts_t: h0..h7 [256] x 8, bottleneck | view encoding [288], view hidden [128] */
+/* floats of acts_t: h0..h7 [256] x 8, bottleneck | view encoding [288], view hidden [128].  acts_t may be NULL in
+ * pn_chain_forward (inference: nothing re-reads the activations; enc_t and the gate words are still written). */
 int64_t pn_chain_acts_floats(int64_t M);
 int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, int planes,
                      const void* pack, const float* mean, const float* cov, const float* viewdirs, float* enc_t,
                      float* acts_t, uint32_t* masks, float* raw_rgb /*[M,3]*/, float* raw_density /*[M,nc]*/,
                      void* stream);
-/* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep; rs_t: T [8][Mp*256] */
+/* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep.  keep_all != 0: rs_t is
+ * T [8][Mp*256] and receives r_0..r_7 (the second-order weight gradients need them); keep_all = 0 (inference): rs_t is ONE
+ * slot T [Mp*256], used only for the kernel's own reload of r_5. */
 int pn_chain_density_grad(int64_t M, int num_density_channels, int planes, float density_bias, const float* params,
                           const void* pack, const float* mean, const float* cov, const uint32_t* masks,
-                          const float* raw_density, float* rs_t, float* grad_mean /*[M,3]*/, void* stream);
+                          const float* raw_density, float* rs_t, int keep_all, float* grad_mean /*[M,3]*/, void* stream);
 /* forward-mode tangent sweep along v_gradmean (the double backward of the normals block) */
 int pn_chain_tangent(int64_t M, int num_density_channels, int planes, const float* params, const void* pack,
                      const float* mean, const float* cov, const uint32_t* masks, const float* v_gradmean,

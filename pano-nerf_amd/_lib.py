@@ -51,7 +51,7 @@ SIGNATURES = {
     "pn_chain_pack": ("i", "piipp"),
     "pn_chain_acts_floats": ("l", "l"),
     "pn_chain_forward": ("i", "lilii" + "p" * 9 + "p"),
-    "pn_chain_density_grad": ("i", "liif" + "p" * 8 + "p"),
+    "pn_chain_density_grad": ("i", "liif" + "p" * 7 + "ipp"),
     "pn_chain_tangent": ("i", "lii" + "p" * 9 + "p"),
     "pn_chain_backward": ("i", "liif" + "p" * 14 + "p"),
     "pn_chain_wgrad_work_floats": ("l", ""),

@@ -639,7 +639,7 @@ __device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], co
 template <int NP>
 __device__ __forceinline__ void finish_gated(accv (&acc)[NT_H], const Gate& m, float* out, BFrag<NP> (&bh)[KS_H]) {
     gate_bits<NT_H>(acc, m);
-    store_t<NT_H>(out, acc);
+    if (out) store_t<NT_H>(out, acc);  // (wave-uniform)
     acc_to_b<NP, NT_H, KS_H>(acc, bh);
 }
 
@@ -653,7 +653,7 @@ struct FwdArgs {
     const float* cov;      // [M,3]
     const float* viewdirs; // [view_rows,3]
     float* enc_t;          // T [96]
-    float* acts_t;         // T: h0..h7 [256] x 8, then bottleneck + view encoding [288], then view hidden [128]
+    float* acts_t;         // T: h0..h7 [256] x 8, then bottleneck + view encoding [288], then view hidden [128]; null: not kept
     uint32_t* masks;       // [9][Mp][8]
     float* raw_rgb;        // [M,3]
     float* raw_den;        // [M,nc]
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         }
         auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T store, next B operand
             relu_bits<NT_H>(acc, mw);
-            store_t<NT_H>(a.acts_t + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);
+            if (a.acts_t) store_t<NT_H>(a.acts_t + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);  // (uniform)
             store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
             acc_to_b<NP, NT_H, KS_H>(acc, bh);
         };
@@ -741,8 +741,8 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         {
             chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
             TR(19);
-            float* bt = a.acts_t + act_off(8, Mp) + T.blk * (288 * TILE) + T.lo;
-            store_t<NT_H>(bt, acc);
+            float* bt = a.acts_t ? a.acts_t + act_off(8, Mp) + T.blk * (288 * TILE) + T.lo : nullptr;
+            if (bt) store_t<NT_H>(bt, acc);
             acc_to_b<NP, NT_H, KS_H + KS_PAD>(acc, bv);
             const int64_t vr = (T.rc / a.rows_per_ray) % a.view_rows;
             float vd[3];
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
                         o = fast_sin(half ? xb + HALF_PI_F : xb);
                     }
                     x[j] = o;
-                    bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = o;
+                    if (bt) bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = o;
                 }
                 split_into<NP>(x, bv[KS_H + q]);
             }
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
             TR(21);
             Gate w4;
             relu_bits<NT_C>(av, w4);
-            store_t<NT_C>(a.acts_t + act_off(9, Mp) + T.blk * (128 * TILE) + T.lo, av);
+            if (a.acts_t) store_t<NT_C>(a.acts_t + act_off(9, Mp) + T.blk * (128 * TILE) + T.lo, av);
             store_gate(a.masks, 8, Mp, T.blk * TILE + T.c, T.g, w4);
             acc_to_b<NP, NT_C, KS_C>(av, bc);
         }
@@ -812,6 +812,7 @@ struct SweepArgs {
     const float* wd0;            // density_layer.weight[0] (256 floats, in the parameter block)
     const float* v;              // [M,3] tangent direction (tangent sweep)
     float* vec_t;                // T [8][256]: r_0..r_7 (reverse sweep) or hdot_0..hdot_7 (tangent sweep)
+    int keep_all;                // reverse sweep: 0 = inference, vec_t is ONE slot and only r_5 is stored (for the reload)
     float* edot_t;               // T [96] (tangent sweep)
     float* out3;                 // [M,3] grad_mean (reverse sweep)
     float* sdot;                 // [M] (tangent sweep)
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         const float sgm = T.live ? ch_sp_d1(a.raw_den[T.rc * a.nc] + a.density_bias) : 0.f;
         BFrag<NP> bh[KS_H];
         {  // seed r_7
-            float* rt = a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo;
+            float* rt = a.keep_all ? a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo : nullptr;
             const Gate m7 = pop_front(mk);
 #pragma unroll
             for (int ks = 0; ks < KS_H; ++ks) {
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
                         const int j = 4 * h + i;
                         const uint32_t bit = (m7.w[(8 * ks + j) >> 5] >> ((8 * ks + j) & 31)) & 1u;
                         x[j] = bit ? sgm * wv[i] : 0.f;
-                        rt[(QB * (2 * ks + h) + i) * TILE] = x[j];
+                        if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = x[j];
                     }
                 }
                 split_into<NP>(x, bh[ks]);
@@ -862,12 +863,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            float* dst = a.keep_all ? a.vec_t + (int64_t)(l - 1) * Mp * 256 : (l - 1 == 5 ? a.vec_t : nullptr);
+            finish_gated<NP>(acc, pop_front(mk), dst ? dst + T.blk * (256 * TILE) + T.lo : nullptr, bh);
         }
         {  // d sigma / d enc over [r_0 | r_5] (two accumulating GEMMs: B_DENC0, B_DENC1), then the encoding's adjoint
             accv a3[NT_ENC];
             chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane);
-            reload_b<NP, KS_H>(a.vec_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            reload_b<NP, KS_H>(a.vec_t + (a.keep_all ? (int64_t)5 * Mp * 256 : 0) + T.blk * (256 * TILE) + T.lo, bh);
             chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane);
             float dm[3];
             ipe_backward_tiles(a3, mu, cv, T.g, dm);
@@ -1481,7 +1483,7 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
                      uint32_t* masks, float* raw_rgb, float* raw_den, void* stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (!pack || !mean || !cov || !viewdirs || !enc_t || !acts_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;
+    if (!pack || !mean || !cov || !viewdirs || !enc_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;  // acts_t may be null
     FwdArgs a{};
     a.M = M;
     a.nst = pn_pad(M) / CH_SAMPLES;
@@ -1498,7 +1500,7 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
  * weight gradients); grad_mean [M,3] = + d sigma / d mean. */
 int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, const float* params, const void* pack,
                           const float* mean, const float* cov, const uint32_t* masks, const float* raw_den, float* rs_t,
-                          float* grad_mean, void* stream) {
+                          int keep_all, float* grad_mean, void* stream) {
     if (M <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
@@ -1516,7 +1518,7 @@ int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, con
     a.nchunk = ball - b7;
     a.masks = masks; a.raw_den = raw_den; a.mean = mean; a.cov = cov;
     a.wd0 = params + pn_layout(nc).wd;
-    a.vec_t = rs_t; a.out3 = grad_mean;
+    a.vec_t = rs_t; a.out3 = grad_mean; a.keep_all = keep_all != 0;
     LAUNCH_CHAIN(k_chain_dgrad, planes, a.nst, a, (hipStream_t)stream, 3, (double)M * kFlopsSweep);
 }
 

@@ -27,7 +27,7 @@ class _Eval:
     """Buffers of one MLP evaluation over M sample rows (all caller-owned HBM).  planes = 0: layer-wise GEMM path
     (row-major activations); planes = 3 / 1: fused chain kernels (T32 sample-minor tensors, see pn_chain.hip)."""
 
-    def __init__(self, M, rows_per_ray, viewdirs, nc, dev, planes=0):
+    def __init__(self, M, rows_per_ray, viewdirs, nc, dev, planes=0, keep=True):
         self.M, self.rows_per_ray, self.nc = M, rows_per_ray, nc
         self.view_rows = viewdirs.shape[0]
         self.viewdirs = viewdirs
@@ -37,8 +37,9 @@ class _Eval:
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.mean, self.cov = e(M, 3), e(M, 3)
         if planes:
-            self.enc = e(Mp * 96)                                          # T32 [96]
-            self.acts = e(int(_lib.load().pn_chain_acts_floats(M)))        # T32 h0..h7, bottleneck | viewenc, view hidden
+            self.enc = e(Mp * 96)                                          # T [96]
+            # T h0..h7, bottleneck | viewenc, view hidden — only the backward re-reads them: not kept in inference
+            self.acts = e(int(_lib.load().pn_chain_acts_floats(M))) if keep else None
         else:
             self.enc = e(Mp, 96)
             self.viewenc, self.viewbias = e(self.view_rows, 27), e(self.view_rows, 128)
@@ -67,7 +68,7 @@ class _Cfg:
 def _mlp_forward(ev, params, wpack, st):
     if ev.planes:
         _lib.call("pn_chain_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, ev.planes, wpack.data_ptr(),
-                  ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), ev.acts.data_ptr(),
+                  ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), _lib.ptr(ev.acts),
                   ev.masks.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), st)
         return
     _lib.call("pn_mlp_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, params.data_ptr(), wpack.data_ptr(),
@@ -200,7 +201,7 @@ class _RenderFn(torch.autograd.Function):
             e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             keep = cfg.keep  # inference (no_grad): release the big activation buffers as soon as possible
             # ---- level 0: stratified samples
-            e0 = _Eval(M, N, vd, nc, dev, planes)
+            e0 = _Eval(M, N, vd, nc, dev, planes, keep)
             e0.t = e(B, S)
             _lib.call("pn_sample_coarse", B, N, o.data_ptr(), d.data_ptr(), radii.data_ptr(), near.data_ptr(),
                       far.data_ptr(), _lib.ptr(t_rand), e0.t.data_ptr(), e0.mean.data_ptr(), e0.cov.data_ptr(), st)
@@ -209,7 +210,7 @@ class _RenderFn(torch.autograd.Function):
             if not keep:
                 e0.acts = e0.masks = e0.enc = None
             # ---- level 1: PDF resample (no gradient through the weights: stop_resample_grad)
-            e1 = _Eval(M, N, vd, nc, dev, planes)
+            e1 = _Eval(M, N, vd, nc, dev, planes, keep)
             e1.t = e(B, S)
             _lib.call("pn_resample", B, N, e0.t.data_ptr(), w0.data_ptr(), cfg.resample_padding, _lib.ptr(u_rand),
                       o.data_ptr(), d.data_ptr(), radii.data_ptr(), e1.t.data_ptr(), e1.mean.data_ptr(),
@@ -219,13 +220,13 @@ class _RenderFn(torch.autograd.Function):
             normal = ort = albedo = surface = diffuse = shading = None
             ee = env_rgb = None
             if cfg.normals:
-                e1.rsweep = e(8, e1.Mp, 256)
+                e1.rsweep = e(8 if (keep or not planes) else 1, e1.Mp, 256)
                 e1.gmean = e(M, 3)
                 scratch = None
                 if planes:
                     _lib.call("pn_chain_density_grad", M, nc, planes, cfg.density_bias, params.data_ptr(),
                               wpack.data_ptr(), e1.mean.data_ptr(), e1.cov.data_ptr(), e1.masks.data_ptr(),
-                              e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), e1.gmean.data_ptr(), st)
+                              e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), int(keep), e1.gmean.data_ptr(), st)
                 else:
                     scratch = e(e1.Mp, 96)
                     _lib.call("pn_density_grad", M, nc, cfg.density_bias, params.data_ptr(), wpack.data_ptr(),
@@ -245,7 +246,7 @@ class _RenderFn(torch.autograd.Function):
                 e1.acts = e1.masks = e1.enc = None
             if cfg.surf:
                 D, Ne = env_d.shape[0], cfg.num_env_samples
-                ee = _Eval(B * D * Ne, Ne, env_d, nc, dev, planes)
+                ee = _Eval(B * D * Ne, Ne, env_d, nc, dev, planes, keep)
                 ee.t = e(B * D, Ne + 1)
                 _lib.call("pn_sample_env", B, D, Ne, o.data_ptr(), d.data_ptr(), dist1.data_ptr(), env_d.data_ptr(),
                           env_rad.data_ptr(), env_near.data_ptr(), env_far.data_ptr(), _lib.ptr(env_rand),

@@ -115,7 +115,7 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc):
     # ---- kernels
     rs_t, gmean = E(8, Mp * 256), E(M, 3)
     _lib.call("pn_chain_density_grad", M, nc, planes, dbias, flat_d.data_ptr(), pack.data_ptr(), mean_d.data_ptr(),
-              cov_d.data_ptr(), ev.masks.data_ptr(), rd.data_ptr(), rs_t.data_ptr(), gmean.data_ptr(), st())
+              cov_d.data_ptr(), ev.masks.data_ptr(), rd.data_ptr(), rs_t.data_ptr(), 1, gmean.data_ptr(), st())
     assert rel(gmean.cpu(), gmean64.detach()) < 5e-5
     v_d, drgb_d, dden_d = v.to(dev()), d_rgb.to(dev()), d_den.to(dev())
     edot_t, tang_t, sdot = E(Mp * 96), E(8, Mp * 256), E(M)

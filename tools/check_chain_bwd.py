@@ -68,7 +68,7 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
               vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(), st())
     rs_t, gmean2 = E(8, Mp * 256), E(M, 3)
     f_dgrad = lambda: _lib.call("pn_chain_density_grad", M, nc, planes, dbias, params.data_ptr(), pack.data_ptr(), mean.data_ptr(),
-                                cov.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(), rs_t.data_ptr(), gmean2.data_ptr(), st())
+                                cov.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(), rs_t.data_ptr(), 1, gmean2.data_ptr(), st())
     f_dgrad()
     edot_t, tang_t, sdot = E(Mp * 96), E(8, Mp * 256), E(M)
     f_tan = lambda: _lib.call("pn_chain_tangent", M, nc, planes, params.data_ptr(), pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
