@@ -25,7 +25,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), same guide
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA (v_mfma_f32_32x32x16_bf16 / _f16), same guide
+DEFAULT_MODE = "fused_f16x2"
 # algorithmic GEMM FLOPs (MACs x 2) per ray per train step, Pano N=128
 F_PANO, F_GRAD = 1222656.0, 1016320.0
 
@@ -106,9 +107,11 @@ def main():
     ap.add_argument("--no-inference", action="store_true", help="skip the full-panorama inference leg (N = 1 only)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
-    ap.add_argument("--mlp-mode", choices=("fused", "fused_bf16", "layerwise"), default=os.environ.get("PN_MLP_MODE", "fused"),
-                    help="fused: on-chip MLP chains, exact 3-term bf16 split (fp32 accuracy; default); fused_bf16: the same "
-                         "kernels with plain bf16 operands (BASELINE configs[1]); layerwise: one GEMM launch per layer")
+    ap.add_argument("--mlp-mode", choices=("fused", "fused_f16x2", "fused_bf16", "layerwise"),
+                    default=os.environ.get("PN_MLP_MODE", DEFAULT_MODE),
+                    help="fused_f16x2 (default): on-chip MLP chains, fp16 pairs with power-of-two scaling, 3 partial products "
+                         "(fp32-class accuracy); fused: the same kernels with the exact 3-term bf16 split, 6 partial products; "
+                         "fused_bf16: plain bf16 operands (BASELINE configs[1]); layerwise: one fp32 GEMM launch per layer")
     ap.add_argument("--streams", default="auto",
                     help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 2 with <= 2048 "
                          "rays per GPU (+4 %% at 512..2048 rays: the chains fill each other's bubbles), else 1 (at 4096 rays "
@@ -144,9 +147,10 @@ def main():
     split = False  # (the layer-wise split GEMM mode of round 1 is gone: the fused chains supersede it)
     peak_nt = PEAK_F32_MFMA_TFLOPS
     fused = args.mlp_mode != "layerwise"
-    # fused chains: v_mfma_f32_32x32x16_bf16, six products per fp32-equivalent product (split) or one (plain bf16)
-    peak_chain = PEAK_BF16_MFMA_TFLOPS / 6.0 if args.mlp_mode == "fused" else PEAK_BF16_MFMA_TFLOPS
-    np_ = 3 if args.mlp_mode == "fused" else 1  # template argument of the fused kernels: bf16 planes per operand
+    # fused chains on the 16-bit matrix cores (2.5 PF dense, bf16 and fp16 alike): six partial products per fp32-equivalent
+    # product (bf16 three-term split), three (fp16 pair) or one (plain bf16)
+    np_ = {"fused": 3, "fused_f16x2": 2, "fused_bf16": 1}.get(args.mlp_mode, 3)  # template argument of the fused kernels
+    peak_chain = PEAK_BF16_MFMA_TFLOPS / {3: 6.0, 2: 3.0, 1: 1.0}[np_]
     # names as rocprofv3 prints them (profiles/*_kernel_stats.csv, profiles/r02_pmc_summary.json)
     CLASSES = ((0, "k_gemm_nt"), (1, "k_gemm_tn"), (2, f"k_chain_fwd<{np_}>"), (3, f"k_chain_dgrad<{np_}>"),
                (4, f"k_chain_tangent<{np_}>"), (5, f"k_chain_bwd<{np_}>"), (6, f"k_chain_wgrad<{np_}, 2, 4, 4, 2>"),
@@ -335,8 +339,9 @@ def main():
             "metric": "rays/sec (train step)", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f32 (3xbf16 split products, fp32 accumulate)" if (split or args.mlp_mode == "fused") else
-                      ("bf16 (fp32 accumulate)" if args.mlp_mode == "fused_bf16" else "f32")), "data": "synthetic",
+            "dtype": {"fused": "f32 (3xbf16 split products, fp32 accumulate)",
+                      "fused_f16x2": "f32 (2xfp16 split products, fp32 accumulate)",
+                      "fused_bf16": "bf16 (fp32 accumulate)"}.get(args.mlp_mode, "f32"), "data": "synthetic",
             "config": {"workload": f"panonerf.yaml train step, synthetic {args.height}x{args.width} pano pool x3 cams, "
                                    f"{args.samples} coarse + {args.samples} fine samples, 10x10 env-light rays, "
                                    f"surface+chrom+ort loss, Adam; global batch {args.global_batch} rays "
@@ -349,9 +354,13 @@ def main():
                        "mlp_mode": args.mlp_mode,
                        "gemm_mode": ("fused on-chip chains (one kernel per forward / reverse sweep / tangent sweep / "
                                      "backward pass, activations in registers, weights by LDS-DMA ring) + T32 weight-gradient "
-                                     "GEMMs, " + ("x = h + m + l (bf16), six partial products on v_mfma_f32_32x32x16_bf16, "
-                                                  "fp32 accumulate (fp32 accuracy)" if args.mlp_mode == "fused" else
-                                                  "plain bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate"))
+                                     "GEMMs, " + {"fused": "x = h + m + l (bf16), six partial products on "
+                                                           "v_mfma_f32_*_bf16, fp32 accumulate (fp32 accuracy)",
+                                                  "fused_f16x2": "x 2^e = h + l (fp16, |error| < 2^-24 |x|; one power-of-two "
+                                                                 "scale per weight matrix and per sample or tensor), three "
+                                                                 "partial products on v_mfma_f32_*_f16, fp32 accumulate",
+                                                  "fused_bf16": "plain bf16 operands on v_mfma_f32_*_bf16, fp32 accumulate"
+                                                  }.get(args.mlp_mode, ""))
                                     if fused else
                                     ("split: x = h + m + l (bf16), six partial products on v_mfma_f32_32x32x16_bf16, fp32 "
                                      "accumulate; weight gradients on fp32 MFMA" if split else "exact fp32 MFMA")},
@@ -369,8 +378,9 @@ def main():
                                   "same kernels in 2 extra steps with the side stream off.  " if args.overlap == "on" else
                                   "all launches on one stream (no time sharing between kernels).  ") +
                                  ("`achieved` and `peak` are fp32-equivalent: algorithmic 2*M*N*K FLOPs per launch against the "
-                                  "dense bf16 MFMA peak (2.5 PF) divided by the six partial products per fp32 product"
-                                  if args.mlp_mode == "fused" else
+                                  "dense 16-bit MFMA peak (2.5 PF) divided by the partial products per fp32 product (six for "
+                                  "the bf16 three-term split, three for the fp16 pair)"
+                                  if args.mlp_mode in ("fused", "fused_f16x2") else
                                   ("`peak` is the dense bf16 MFMA figure (2.5 PF)" if args.mlp_mode == "fused_bf16" else
                                    "`peak` is the 2.4 GHz datasheet figure; under the power cap the same k_gemm_nt binary runs "
                                    "126 TF on zero/constant operands and 101 TF on N(0,1) operands (tools/bench_clock.py, "

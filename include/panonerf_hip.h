@@ -173,8 +173,10 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_dens
  * The same MLP (models/pano_mip_nerf.py:95-114, models/mip_nerf.py:81-102), encodings (models/mip.py:394-441) and
  * their reverse / forward-mode passes as ONE kernel per pass: every layer is computed transposed on
  * v_mfma_f32_32x32x16_bf16, a wave carries the activations of its 32 samples from layer to layer in registers, the
- * weights stream through an LDS ring by LDS-DMA.  planes = 3: exact 3-term bf16 split (fp32 accuracy); planes = 1:
- * plain bf16 operands, fp32 accumulate.  Sample-row tensors these kernels exchange are in the "T layout":
+ * weights stream through an LDS ring by LDS-DMA.  planes = 3: exact 3-term bf16 split, six partial products (fp32
+ * accuracy); planes = 2: fp16 pairs (x 2^e = h + l, |error| < 2^-24 |x|), three partial products, one power-of-two scale
+ * per weight matrix and per sample (chains) or per tensor (weight gradients), fp32 accumulate; planes = 1: plain bf16
+ * operands, fp32 accumulate.  Sample-row tensors these kernels exchange are in the "T layout":
  * float[Mp/tile][F][tile] (sample-minor, tile = pn_chain_tile(), Mp = pn_pad_rows(M)); gate words are uint32 [9][Mp][8]
  * (per row: tile-dependent lane-group order, see pn_chain.hip; producers and consumers are all in this library). */
 /* samples per block of the sample-minor tensors (= samples per wave of the chain kernels): 16 (v_mfma_f32_16x16x32_bf16,
@@ -186,27 +188,33 @@ int pn_chain_pack(const float* params, int num_density_channels, int planes, voi
 /* floats of acts_t: h0..h7 [256] x 8, bottleneck | view encoding [288], view hidden [128].  acts_t may be NULL in
  * pn_chain_forward (inference: nothing re-reads the activations; enc_t and the gate words are still written). */
 int64_t pn_chain_acts_floats(int64_t M);
+/* amax (planes = 2, training; NULL otherwise): ONE evaluation's table of pn_chain_amax_slots() uint32, the largest |x| of
+ * every T tensor the weight gradients will read (float bits).  pn_chain_forward clears it, the four chain kernels of the
+ * evaluation add their tensors' maxima, pn_chain_wgrad derives one power-of-two scale per tensor from it. */
+int pn_chain_amax_slots(void);
 int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, int planes,
                      const void* pack, const float* mean, const float* cov, const float* viewdirs, float* enc_t,
                      float* acts_t, uint32_t* masks, float* raw_rgb /*[M,3]*/, float* raw_density /*[M,nc]*/,
-                     void* stream);
+                     uint32_t* amax, void* stream);
 /* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep.  keep_all != 0: rs_t is
  * T [8][Mp*256] and receives r_0..r_7 (the second-order weight gradients need them); keep_all = 0 (inference): rs_t is ONE
  * slot T [Mp*256], used only for the kernel's own reload of r_5. */
 int pn_chain_density_grad(int64_t M, int num_density_channels, int planes, float density_bias, const float* params,
                           const void* pack, const float* mean, const float* cov, const uint32_t* masks,
-                          const float* raw_density, float* rs_t, int keep_all, float* grad_mean /*[M,3]*/, void* stream);
+                          const float* raw_density, float* rs_t, int keep_all, float* grad_mean /*[M,3]*/,
+                          uint32_t* amax, void* stream);
 /* forward-mode tangent sweep along v_gradmean (the double backward of the normals block) */
 int pn_chain_tangent(int64_t M, int num_density_channels, int planes, const float* params, const void* pack,
                      const float* mean, const float* cov, const uint32_t* masks, const float* v_gradmean,
-                     float* edot_t /*T [Mp*96]*/, float* tang_t /*T [8][Mp*256]*/, float* sdot /*[M]*/, void* stream);
+                     float* edot_t /*T [Mp*96]*/, float* tang_t /*T [8][Mp*256]*/, float* sdot /*[M]*/, uint32_t* amax,
+                     void* stream);
 /* data-gradient chain.  drgb_t T [Mp*32], d8_t T [Mp*288], coef_t T [Mp*32] must be zero-filled by the caller
  * once (the kernel rewrites the rows it owns); sdot / coef_t: second-order path (both or neither); d_mean nullable. */
 int pn_chain_backward(int64_t M, int num_density_channels, int planes, float density_bias, const void* pack,
                       const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
                       const float* d_raw_density, const float* sdot, const float* mean, const float* cov,
                       float* drgb_t, float* dhv_t /*T [Mp*128]*/, float* d8_t, float* delta_t /*T [8][Mp*256]*/,
-                      float* coef_t, float* d_mean /*[M,3]*/, void* stream);
+                      float* coef_t, float* d_mean /*[M,3]*/, uint32_t* amax, void* stream);
 /* one evaluation's tensors for the weight gradients (host struct of device pointers) */
 typedef struct PnChainEval {
     int64_t M;
@@ -220,6 +228,7 @@ typedef struct PnChainEval {
     const float* edot_t;
     const float* tang_t;
     const float* coef_t;
+    const uint32_t* amax; /* planes = 2: the evaluation's table of maxima; NULL otherwise */
 } PnChainEval;
 int64_t pn_chain_wgrad_work_floats(void);
 int pn_chain_wgrad(int n_evals, const PnChainEval* evals_host, int num_density_channels, int planes, float* grads,

@@ -50,10 +50,11 @@ SIGNATURES = {
     "pn_chain_pack_bytes": ("l", "i"),
     "pn_chain_pack": ("i", "piipp"),
     "pn_chain_acts_floats": ("l", "l"),
-    "pn_chain_forward": ("i", "lilii" + "p" * 9 + "p"),
-    "pn_chain_density_grad": ("i", "liif" + "p" * 7 + "ipp"),
-    "pn_chain_tangent": ("i", "lii" + "p" * 9 + "p"),
-    "pn_chain_backward": ("i", "liif" + "p" * 14 + "p"),
+    "pn_chain_amax_slots": ("i", ""),
+    "pn_chain_forward": ("i", "lilii" + "p" * 10 + "p"),
+    "pn_chain_density_grad": ("i", "liif" + "p" * 7 + "ippp"),
+    "pn_chain_tangent": ("i", "lii" + "p" * 10 + "p"),
+    "pn_chain_backward": ("i", "liif" + "p" * 15 + "p"),
     "pn_chain_wgrad_work_floats": ("l", ""),
     "pn_chain_wgrad": ("i", "ipiipplp"),
     "pn_mfma_probe": ("i", "piip"),

@@ -32,13 +32,18 @@
 #include "pn_common.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 #ifndef PN_CHAIN_TILE
 #define PN_CHAIN_TILE 16
+#endif
+#ifndef PN_ABL_CHAIN  // timing ablations of the GEMM step (wrong results; never in the shipped build): bit 0 no refill DMA,
+#define PN_ABL_CHAIN 0  // bit 1 no fragment reads, bit 2 no MFMAs, bit 3 no ring barrier
 #endif
 #define HALF_PI_F 1.5707963705062866f
 constexpr int TILE = PN_CHAIN_TILE;  // features per accumulator tile = samples per wave
@@ -52,9 +57,11 @@ constexpr int ACCR = 4 * ACCQ;       // accumulator registers per tile
 #define PN_CHAIN_WAVES 4
 #endif
 // Waves per workgroup.  TILE 32: 4 (one per SIMD, up to 512 registers).  TILE 16: 4 waves of <= 256 registers and a 3-slot
-// ring, so TWO INDEPENDENT workgroups share a CU: a workgroup-wide barrier per chunk keeps the waves of ONE workgroup in
-// lockstep (8 waves in one workgroup did their epilogues together and gained nothing), two workgroups drift apart and one's
-// epilogue / encoding / DMA issue runs under the other's MFMAs.
+// ring, so TWO INDEPENDENT workgroups share a CU (one wave of each per SIMD; a workgroup-wide barrier per chunk keeps the
+// waves of ONE workgroup in lockstep, and 8 waves in one workgroup gained nothing).  What the second wave buys is
+// measured, not assumed: timing ablations (PN_ABL_CHAIN) show a kernel's time to be close to the SUM of its MFMA time and
+// of its VALU / store time - a 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles, so the neighbour's
+// epilogue and this wave's products mostly take turns (starting the second workgroup half a layer late changed nothing).
 constexpr int CH_WAVES = PN_CHAIN_WAVES;
 constexpr int CH_THREADS = 64 * CH_WAVES;
 constexpr int CH_SAMPLES = CH_WAVES * TILE;                    // samples per workgroup tile
@@ -70,18 +77,26 @@ constexpr int KS_C = 128 / KSTEP, NT_C = 128 / TILE;      // the 128-wide view h
 template <int NP>
 struct Cfg {
     // fragments (1 KB each) per chunk; with two workgroups per CU a ring of three slots must stay under 80 KB
-    static constexpr int CF = NP == 3 ? 24 : (CH_WG_PER_CU == 2 ? 16 : 32);
+    static constexpr int CF = NP >= 2 ? 24 : (CH_WG_PER_CU == 2 ? 16 : 32);
     static constexpr int PER = CF / NP;                // GEMM steps (one A fragment set each) per chunk
     static constexpr int SLOT = (CF + 1) * 1024;       // + 1 KB of aux floats (bias) per chunk
-    static constexpr int NSLOT = CH_WG_PER_CU == 2 ? 3 : (NP == 3 ? 5 : 4);  // ring slots
+    static constexpr int NSLOT = CH_WG_PER_CU == 2 ? 3 : (NP >= 2 ? 5 : 4);  // ring slots
     static constexpr int D = NSLOT - 1;                // chunks in flight ahead of the one being consumed
     static constexpr int SHARE = CF / CH_WAVES;        // DMA instructions EVERY wave issues per chunk (waves 0-3 one more)
     static constexpr int LDS_BYTES = SLOT * NSLOT;
 };
 
 template <int NP>
+struct PlaneOf {
+    typedef bf16x8 type;
+};
+template <>
+struct PlaneOf<2> {
+    typedef f16x8 type;
+};
+template <int NP>
 struct BFrag {
-    bf16x8 p[NP];
+    typename PlaneOf<NP>::type p[NP];
 };
 
 // feature held by lane group g in position i of quad block qb
@@ -145,8 +160,39 @@ struct PackTable {
     int n, nchunks;
 };
 
+// NP = 2 only: one power-of-two scale per packed GEMM, 2^wexp, that takes the largest |weight| of its segments into
+// [2^14, 2^15) (fp16 holds 65504), clamped to 2^+-40.  One workgroup per GEMM of the table.
+constexpr int EXP_TOP = 15;   // frexp exponent of the scaled maximum
+constexpr int EXP_CLAMP = 40;
+__device__ __forceinline__ int scale_exp(float amax) {
+    const int e = EXP_TOP - __builtin_amdgcn_frexp_expf(amax);
+    return e < -EXP_CLAMP ? -EXP_CLAMP : (e > EXP_CLAMP ? EXP_CLAMP : e);
+}
+__global__ void k_chain_wexp(PackTable tab, const float* params, int* wexp) {
+    const PackLayer& L = tab.L[blockIdx.x];
+    float m = 0.f;
+    for (int s = 0; s < L.nseg; ++s) {
+        const PackSeg& sg = L.seg[s];
+        const int n = L.rows_valid * sg.kvalid;
+        for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+            const int i = idx / sg.kvalid, kr = idx - i * sg.kvalid;
+            const float x = sg.transposed ? params[sg.off + (int64_t)kr * sg.ld + sg.col0 + i]
+                                          : params[sg.off + (int64_t)i * sg.ld + sg.col0 + kr];
+            m = fmaxf(m, fabsf(x));
+        }
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wexp[blockIdx.x] = scale_exp(red[0]);
+}
+
 template <int NP>
-__global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* out) {
+__global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* out, const int* wexp) {
     constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT, PER = Cfg<NP>::PER;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
@@ -183,21 +229,46 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
                         x = sg.transposed ? params[sg.off + (int64_t)kr * sg.ld + sg.col0 + i]
                                           : params[sg.off + (int64_t)i * sg.ld + sg.col0 + kr];
                 }
-            const __bf16 hb = (__bf16)x;
-            __bf16 r = hb;
-            if (p >= 1) {
-                const float r1 = x - (float)hb;
-                const __bf16 mb = (__bf16)r1;
-                r = mb;
-                if (p == 2) r = (__bf16)(r1 - (float)mb);
-            }
             unsigned short bits;
-            __builtin_memcpy(&bits, &r, 2);
+            if constexpr (NP == 2) {  // fp16 pair of the scaled weight
+                const float t = ldexpf(x, wexp[li]);
+                const _Float16 hh = (_Float16)t;
+                const _Float16 r = p == 0 ? hh : (_Float16)(t - (float)hh);
+                __builtin_memcpy(&bits, &r, 2);
+            } else {
+                const __bf16 hb = (__bf16)x;
+                __bf16 r = hb;
+                if (p >= 1) {
+                    const float r1 = x - (float)hb;
+                    const __bf16 mb = (__bf16)r1;
+                    r = mb;
+                    if (p == 2) r = (__bf16)(r1 - (float)mb);
+                }
+                __builtin_memcpy(&bits, &r, 2);
+            }
             o[j] = bits;
         }
     }
     memcpy(dst, o, 16);
 }
+
+#ifdef PN_TRACE_CHAIN  // debug build only (PN_EXTRA=-DPN_TRACE_CHAIN): shader-clock stamps of one wave's second tile
+__device__ unsigned long long g_chain_trace[64];
+extern "C" int pn_chain_trace_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
+}
+#define TR(i)                                                                                          \
+    do {                                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && st == (int64_t)gridDim.x) g_chain_trace[i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define TRX(i)                                                                                 \
+    do {                                                                                       \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_chain_trace[i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TR(i)
+#define TRX(i)
+#endif
 
 // ------------------------------------------------------------------------------------------------ the weight ring
 // All waves issue their share of every chunk's DMA and all consume every chunk.  acquire(): wait for my share of the
@@ -222,23 +293,27 @@ struct Ring {
         pf = (pf + 1 == nchunk) ? 0 : pf + 1;
         pslot = (pslot + 1 == Cfg<NP>::NSLOT) ? 0 : pslot + 1;
     }
-    template <int I>
+    // An LDS-DMA instruction costs the issuing wave 60-185 cycles whatever it carries (MI355X_MICROARCH.md, cycle
+    // constants) and a wave's GEMM phase is paced by that, so the aux KB travels only with the rounds that can refill the
+    // FIRST chunk of a GEMM with a bias (AUX; decided statically by the GEMM step: a run-time test cost far more than the
+    // instruction - its branch splits the step sequence into blocks with full waits at their joins).
+    template <int I, bool AUX>
     __device__ __forceinline__ void piece() {
         if constexpr (I < CF / CH_WAVES) {
             const int f = wid + CH_WAVES * I;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(cur_lds + f * 1024), 16, lane * 16, cur_soff + f * 1024, 0, 0);
-        } else if constexpr (I == CF / CH_WAVES) {
+        } else if constexpr (I == CF / CH_WAVES && AUX) {
             if (wid < 4) {  // wave-uniform
                 const int o = CF * 1024 + wid * 256;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(cur_lds + o), 4, lane * 4, cur_soff + o, 0, 0);
             }
         }
     }
-    template <int I0, int STRIDE>
+    template <int I0, int STRIDE, bool AUX = true>
     __device__ __forceinline__ void pieces_from() {  // pieces I0, I0 + STRIDE, ... of the current round
         if constexpr (I0 < PIECES) {
-            piece<I0>();
-            pieces_from<I0 + STRIDE, STRIDE>();
+            piece<I0, AUX>();
+            pieces_from<I0 + STRIDE, STRIDE, AUX>();
         }
     }
     __device__ __forceinline__ void start(const unsigned char* s, unsigned char* l, int n, int w, int ln, int first) {
@@ -249,13 +324,28 @@ struct Ring {
 #pragma unroll
         for (int i = 0; i < Cfg<NP>::D; ++i) {
             begin_round();
-            pieces_from<0, 1>();
+            pieces_from<0, 1, true>();
         }
     }
+#ifdef PN_TRACE_CHAIN
+    unsigned long long t_lds = 0, t_dma = 0, t_bar = 0, n_acq = 0;
+#endif
     __device__ __forceinline__ uint32_t acquire() {
         constexpr int N = Cfg<NP>::SHARE * (Cfg<NP>::D - 1);
+#ifdef PN_TRACE_CHAIN
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t_lds += t1 - t0; t_dma += t2 - t1; t_bar += t3 - t2; ++n_acq;
+#else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+        if constexpr (!(PN_ABL_CHAIN & 8)) __builtin_amdgcn_s_barrier();
+#endif
         begin_round();
         const uint32_t p = lds_addr + cslot * SLOT;
         cslot = (cslot + 1 == Cfg<NP>::NSLOT) ? 0 : cslot + 1;
@@ -264,6 +354,11 @@ struct Ring {
     __device__ __forceinline__ void drain() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef PN_TRACE_CHAIN
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            g_chain_trace[56] = t_lds; g_chain_trace[57] = t_dma; g_chain_trace[58] = t_bar; g_chain_trace[59] = n_acq;
+        }
+#endif
     }
 };
 
@@ -275,12 +370,23 @@ __device__ __forceinline__ accv mfma1(const bf16x8& a, const bf16x8& b, accv v) 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, v, 0, 0, 0);
 #endif
 }
+__device__ __forceinline__ accv mfma1(const f16x8& a, const f16x8& b, accv v) {
+#if PN_CHAIN_TILE == 32
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, v, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, v, 0, 0, 0);
+#endif
+}
 template <int NP>
 __device__ __forceinline__ accv mfma_split(const BFrag<NP>& a, const BFrag<NP>& b, accv v) {
     if constexpr (NP == 3) {  // small terms first
         v = mfma1(a.p[2], b.p[0], v);
         v = mfma1(a.p[0], b.p[2], v);
         v = mfma1(a.p[1], b.p[1], v);
+        v = mfma1(a.p[1], b.p[0], v);
+        v = mfma1(a.p[0], b.p[1], v);
+        v = mfma1(a.p[0], b.p[0], v);
+    } else if constexpr (NP == 2) {
         v = mfma1(a.p[1], b.p[0], v);
         v = mfma1(a.p[0], b.p[1], v);
         v = mfma1(a.p[0], b.p[0], v);
@@ -303,48 +409,119 @@ template <int NP, int LEFT>
 __device__ __forceinline__ void wait_a(BFrag<NP>& a) {
     if constexpr (NP == 3)
         asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a.p[0]), "+v"(a.p[1]), "+v"(a.p[2]) : "n"(LEFT) : "memory");
+    else if constexpr (NP == 2)
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.p[0]), "+v"(a.p[1]) : "n"(LEFT) : "memory");
     else
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a.p[0]) : "n"(LEFT) : "memory");
 }
-// step S0 of a GEMM of KS x NT steps (k-step major): fragments of step S0 + 1 are read before the MFMAs of step S0, across
-// chunk boundaries too (the next chunk is acquired while the last fragments of the current one are in registers)
-template <int NP, int KS, int NT, int S0>
+// Steps per unit.  U = 2 runs two feature tiles of the same k-step with their products interleaved (dependent products
+// two issue slots apart).  Measured: no gain (NP = 2 forward 2.34 -> 2.52 ms with the extra fragment registers): a chain of
+// dependent 16x16x32 products already issues at full rate, so every GEMM runs single steps.
+template <int NP, int NT>
+struct Unit {
+    static constexpr int U = 1;
+};
+// Fragment look-ahead, in GEMM steps (a multiple of the unit): an LDS read takes ~110-130 cycles, a step's MFMAs
+// 16 NP (NP + 1) / 2.  (Also measured without effect on the NP = 2 step time, 1 vs 3 vs 4 steps: a wave's GEMM phase is
+// paced by its LDS-DMA issue, see Ring.)
+template <int NP>
+struct Look {
+    static constexpr int N = NP == 3 ? 1 : 3;
+};
+// steps of chunk c of a GEMM of S steps
+template <int NP>
+__host__ __device__ constexpr int chunk_steps(int S, int c) {
+    return (c == (S - 1) / Cfg<NP>::PER && S % Cfg<NP>::PER) ? S % Cfg<NP>::PER : Cfg<NP>::PER;
+}
+// fragments of step PP (if the GEMM has one): the chunk is acquired when the look-ahead reaches its first step (every
+// read of the chunk before it has been issued by then)
+template <int NP, int S, int PP>
+__device__ __forceinline__ void read_step(Ring<NP>& R, uint32_t& sa, int lane, BFrag<NP>& f) {
+    if constexpr (PP < S) {
+        if constexpr (PP % Cfg<NP>::PER == 0) sa = R.acquire() + lane * 16;
+        if constexpr (PN_ABL_CHAIN & 2) f = BFrag<NP>{};
+        else read_a<NP, PP % Cfg<NP>::PER>(f, sa);
+    }
+}
+// The share of the refill round (opened by the acquire of PP's chunk) that look-ahead position PP stands for.  The round
+// of chunk c refills the chunk D after it: with BIASNEXT (a forward chain whose biases are read) the rounds of a GEMM's
+// last D chunks carry the aux KB - they are the ones that can reach the first chunk of a later GEMM.
+template <int NP, int S, int PP, bool BIASNEXT>
+__device__ __forceinline__ void piece_step(Ring<NP>& R) {
+    if constexpr (PP < S && !(PN_ABL_CHAIN & 1)) {
+        constexpr int PER = Cfg<NP>::PER, c = PP / PER, n = (S + PER - 1) / PER;
+        R.template pieces_from<PP % PER, chunk_steps<NP>(S, c), (BIASNEXT && c + Cfg<NP>::D >= n)>();
+    }
+}
+template <int NP>
+__device__ __forceinline__ void tie(BFrag<NP>& a) {  // orders a use of `a` after the wait asm before it
+    if constexpr (NP == 3) asm volatile("" : "+v"(a.p[0]), "+v"(a.p[1]), "+v"(a.p[2]));
+    else if constexpr (NP == 2) asm volatile("" : "+v"(a.p[0]), "+v"(a.p[1]));
+    else asm volatile("" : "+v"(a.p[0]));
+}
+__device__ __forceinline__ void mfma_pair(const BFrag<2>& a0, const BFrag<2>& a1, const BFrag<2>& b, accv& v0, accv& v1) {
+    v0 = mfma1(a0.p[1], b.p[0], v0);
+    v1 = mfma1(a1.p[1], b.p[0], v1);
+    v0 = mfma1(a0.p[0], b.p[1], v0);
+    v1 = mfma1(a1.p[0], b.p[1], v1);
+    v0 = mfma1(a0.p[0], b.p[0], v0);
+    v1 = mfma1(a1.p[0], b.p[0], v1);
+}
+// unit S0 .. S0 + U - 1 of a GEMM of KS x NT steps (k-step major): q[0..U) hold its fragments, q[U..] those of the steps
+// after it; the fragments of steps S0 + LA .. are read before the unit's MFMAs, across chunk boundaries too; the unit then
+// issues the shares of the refill round that those look-ahead positions stand for.
+template <int NP, int KS, int NT, int S0, bool BIASNEXT>
 struct GemmStep {
+    static constexpr int LA = Look<NP>::N, U = Unit<NP, NT>::U;
+    static_assert(LA >= U && LA % U == 0 && (KS * NT) % U == 0, "look-ahead in whole units");
     static __device__ __forceinline__ void run(Ring<NP>& R, const BFrag<NP> (&b)[KS], accv (&acc)[NT], uint32_t& sa,
-                                               BFrag<NP>& a, int lane) {
-        constexpr int PER = Cfg<NP>::PER, S = KS * NT;
-        constexpr int r = S0 % PER;                                   // position in the chunk
-        constexpr int csteps = (S0 / PER == (S - 1) / PER && S % PER) ? S % PER : PER;  // steps of this chunk
-        constexpr bool more = S0 + 1 < S, in_chunk = r + 1 < PER;
-        BFrag<NP> an;
-        if constexpr (more) {
-            if constexpr (in_chunk) {
-                read_a<NP, r + 1>(an, sa);
-            } else {
-                sa = R.acquire() + lane * 16;
-                read_a<NP, 0>(an, sa);
-            }
-        }
-        wait_a<NP, more ? NP : 0>(a);
+                                               BFrag<NP> (&q)[LA], int lane) {
+        constexpr int S = KS * NT;
+        constexpr int hi = (S0 + LA + U) < S ? (S0 + LA + U) : S;
+        constexpr int young = hi > S0 + U ? hi - (S0 + U) : 0;  // fragment sets younger than the unit's in flight
+        BFrag<NP> nw[U];
+        read_step<NP, S, S0 + LA>(R, sa, lane, nw[0]);
+        if constexpr (U == 2) read_step<NP, S, S0 + LA + 1>(R, sa, lane, nw[1]);
+        wait_a<NP, NP * young>(q[0]);
         constexpr int ks = S0 / NT, t = S0 % NT;
-        acc[t] = mfma_split<NP>(a, b[ks], acc[t]);
+        if constexpr (U == 2) {
+            tie<NP>(q[1]);
+            mfma_pair(q[0], q[1], b[ks], acc[t], acc[t + 1]);
+        } else if constexpr (!(PN_ABL_CHAIN & 4)) {
+            acc[t] = mfma_split<NP>(q[0], b[ks], acc[t]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        // this step's share of the refill round its chunk's acquire opened.  Careful: when the NEXT chunk was just
-        // acquired above (r + 1 == PER), the round now open belongs to that chunk: its pieces start with its own steps.
-        if constexpr (in_chunk || !more) R.template pieces_from<r, csteps>();
+        piece_step<NP, S, S0 + LA, BIASNEXT>(R);
+        if constexpr (U == 2) piece_step<NP, S, S0 + LA + 1, BIASNEXT>(R);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (more) {
-            a = an;
-            GemmStep<NP, KS, NT, S0 + 1>::run(R, b, acc, sa, a, lane);
+        if constexpr (S0 + U < S) {
+#pragma unroll
+            for (int i = 0; i + U < LA; ++i) q[i] = q[i + U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) q[LA - U + u] = nw[u];
+            GemmStep<NP, KS, NT, S0 + U, BIASNEXT>::run(R, b, acc, sa, q, lane);
         }
     }
 };
+// the first LA steps' fragments of a GEMM (chunk 0, just acquired) and their shares of its refill round
+template <int NP, int S, int I, bool BIASNEXT>
+__device__ __forceinline__ void gemm_prologue(Ring<NP>& R, uint32_t sa, BFrag<NP> (&q)[Look<NP>::N]) {
+    if constexpr (I < Look<NP>::N && I < S) {
+        read_a<NP, I>(q[I], sa);
+        piece_step<NP, S, I, BIASNEXT>(R);
+        gemm_prologue<NP, S, I + 1, BIASNEXT>(R, sa, q);
+    }
+}
 // acc[t] (+)= W-chunks * b[0..KS).  The first chunk's aux KB holds the layer's bias (when BIAS): it initialises the
 // accumulators (position i of quad block qb <- bias[feat(qb, g, i)]).
-template <int NP, int KS, int NT, bool BIAS, bool ZERO>
-__device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS], accv (&acc)[NT], int lane) {
+//
+// NP = 2 works in scaled units: the weights of the GEMM carry 2^wexp and the B operand of this lane's sample 2^bex, so
+// the MFMAs accumulate 2^sc times the true sums (sc = wexp + bex, per lane: an accumulator register belongs to ONE
+// sample).  Bias / running sums enter multiplied by 2^sc and the result leaves divided by it: exact (powers of two).
+template <int NP, int KS, int NT, bool BIAS, bool ZERO, bool BIASNEXT = false>
+__device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS], accv (&acc)[NT], int lane, int sc = 0) {
     constexpr int CF = Cfg<NP>::CF;
-    static_assert(Ring<NP>::PIECES < Cfg<NP>::PER, "the last step of a full chunk issues no DMA piece");
+    static_assert(Look<NP>::N <= Cfg<NP>::PER, "the look-ahead stays within one chunk boundary");
     const uint32_t s0 = R.acquire();
     if constexpr (BIAS) {
         const float* aux = reinterpret_cast<const float*>(R.lds + (s0 - R.lds_addr) + CF * 1024) + 4 * (lane / TILE);
@@ -353,10 +530,10 @@ __device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS]
 #pragma unroll
             for (int q = 0; q < ACCQ; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(aux + QB * (ACCQ * t + q));
-                acc[t][4 * q] = v[0];
-                acc[t][4 * q + 1] = v[1];
-                acc[t][4 * q + 2] = v[2];
-                acc[t][4 * q + 3] = v[3];
+                acc[t][4 * q] = NP == 2 ? ldexpf(v[0], sc) : v[0];
+                acc[t][4 * q + 1] = NP == 2 ? ldexpf(v[1], sc) : v[1];
+                acc[t][4 * q + 2] = NP == 2 ? ldexpf(v[2], sc) : v[2];
+                acc[t][4 * q + 3] = NP == 2 ? ldexpf(v[3], sc) : v[3];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not see the asm reads that follow
     } else if constexpr (ZERO) {
@@ -364,42 +541,153 @@ __device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS]
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < ACCR; ++e) acc[t][e] = 0.f;
+    } else if constexpr (NP == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < ACCR; ++e) {
+                const float x = acc[t][e];
+                acc[t][e] = ldexpf(x, sc);
+            }
     }
     uint32_t sa = s0 + lane * 16;
-    BFrag<NP> a;
-    read_a<NP, 0>(a, sa);
-    GemmStep<NP, KS, NT, 0>::run(R, b, acc, sa, a, lane);
+    BFrag<NP> q[Look<NP>::N];
+    gemm_prologue<NP, KS * NT, 0, BIASNEXT>(R, sa, q);
+    GemmStep<NP, KS, NT, 0, BIASNEXT>::run(R, b, acc, sa, q, lane);
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < ACCR; ++e) {
+                const float x = acc[t][e];
+                acc[t][e] = ldexpf(x, -sc);
+            }
+    }
 }
 
 // --------------------------------------------------------------------------------------------- register plumbing
+// NP = 2: x * 2^ex = h + l in fp16 (11 + 11 significant bits and the sign of l: the error is below 2^-24 |x| while
+// l stays normal, and below 2^-39 of the column's largest element otherwise); NP = 3: x = h + m + l in bf16, exactly.
 template <int NP>
-__device__ __forceinline__ void split_into(const float (&x)[8], BFrag<NP>& f) {
+__device__ __forceinline__ void split_into(const float (&x)[8], BFrag<NP>& f, int ex = 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        f.p[0][j] = h;
-        if constexpr (NP == 3) {
-            const float r1 = x[j] - (float)h;
-            const __bf16 m = (__bf16)r1;
-            f.p[1][j] = m;
-            f.p[2][j] = (__bf16)(r1 - (float)m);
+        if constexpr (NP == 2) {
+            const float t = ldexpf(x[j], ex);
+            const _Float16 h = (_Float16)t;
+            f.p[0][j] = h;
+            f.p[1][j] = (_Float16)(t - (float)h);
+        } else {
+            const __bf16 h = (__bf16)x[j];
+            f.p[0][j] = h;
+            if constexpr (NP == 3) {
+                const float r1 = x[j] - (float)h;
+                const __bf16 m = (__bf16)r1;
+                f.p[1][j] = m;
+                f.p[2][j] = (__bf16)(r1 - (float)m);
+            }
         }
     }
+}
+// The exponent of a B operand (NP = 2) and, for the weight-gradient GEMMs that read the same values back from their T
+// tensor, the largest |x| over the wave's samples (float bits; 0 when not NP = 2).
+struct Ex {
+    int ex;
+    uint32_t top;
+};
+// largest |x| of this lane's SAMPLE from the largest |x| this lane holds of it (the lane groups of a column are reduced)
+__device__ __forceinline__ float col_max(float m) {
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if constexpr (NG == 4) m = fmaxf(m, __shfl_xor(m, 16, 64));
+    return m;
+}
+// maximum over the 16 lanes of a DPP row (every lane ends with it); bit patterns of non-negative floats order as integers
+__device__ __forceinline__ uint32_t row_umax(uint32_t v) {
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v = v > o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v = v > o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v = v > o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+    v = v > o ? v : o;
+    return v;
+}
+// column maximum -> the operand's exponent (the column's maximum goes to [2^14, 2^15)) + the wave's maximum
+__device__ __forceinline__ Ex ex_of(float lane_max) {
+    const float cm = col_max(lane_max);
+    Ex e;
+    e.ex = scale_exp(cm);
+    uint32_t v = row_umax(__float_as_uint(cm));
+    if constexpr (NG == 2) {  // 32 sample columns: two rows of 16
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, 16, 64);
+        v = v > o ? v : o;
+    }
+    e.top = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return e;
+}
+// Running maxima of a kernel's T tensors over all tiles of a wave (wave-uniform values; static indices only), added to
+// the evaluation's table at the end: the weight-gradient GEMMs (NP = 2) scale each tensor by ONE power of two.
+template <int N>
+struct RunMax {
+    uint32_t v[N];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = 0u;
+    }
+    __device__ __forceinline__ void upd(int idx, uint32_t x) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = (idx == k && x > v[k]) ? x : v[k];
+    }
+    __device__ __forceinline__ void flush(uint32_t* slots, int lane) const {
+        if (slots && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                if (v[k]) atomicMax(slots + k, v[k]);
+        }
+    }
+};
+// slots of an evaluation's table of maxima (uint32 float bits, AM_COUNT per evaluation)
+enum {
+    AM_ENC = 0, AM_ACT0 = 1 /* h0..h7, [bottleneck | view encoding], view hidden */, AM_DELTA0 = 11 /* delta_0..7 */,
+    AM_D8B = 19, AM_D8D = 20, AM_DHV = 21, AM_DRGB = 22, AM_RS0 = 23 /* r_0..7 */, AM_TANG0 = 31 /* hdot_0..7 */,
+    AM_EDOT = 39, AM_COEF = 40, AM_COUNT = 64
+};
+template <int NT>
+__device__ __forceinline__ float lane_amax(const accv (&acc)[NT]) {
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < ACCR; ++e) {
+            const float x = acc[t][e];
+            m = fmaxf(m, fabsf(x));
+        }
+    return m;
 }
 // value at position i of quad block qb of a vector held as accumulator tiles
 #define AQ(acc, qb, i) (acc)[(qb) / ACCQ][4 * ((qb) % ACCQ) + (i)]
 // accumulator tiles (NT tiles = NT * ACCQ / 2 k-steps of quad-block pairs) -> the first k-steps of a B operand
 template <int NP, int NT, int KB>
-__device__ __forceinline__ void acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB]) {
-    constexpr int KS = NT * ACCQ / 2;
-    static_assert((NT * ACCQ) % 2 == 0 && KS <= KB, "quad blocks");
+__device__ __forceinline__ void split_acc(const accv (&acc)[NT], BFrag<NP> (&b)[KB], int ex) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+    for (int s = 0; s < NT * ACCQ / 2; ++s) {
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = AQ(acc, 2 * s + (j >> 2), j & 3);
-        split_into<NP>(x, b[s]);
+        split_into<NP>(x, b[s], ex);
     }
+}
+// Returns the operand's exponent (NP = 2; `also`: largest |x| of further elements the caller appends to the operand).
+template <int NP, int NT, int KB>
+__device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB], float also = 0.f) {
+    constexpr int KS = NT * ACCQ / 2;
+    static_assert((NT * ACCQ) % 2 == 0 && KS <= KB, "quad blocks");
+    Ex e{0, 0u};
+    if constexpr (NP == 2) e = ex_of(fmaxf(lane_amax<NT>(acc), also));
+    split_acc<NP, NT, KB>(acc, b, e.ex);
+    return e;
 }
 // T-layout store: base points at [block][0][0] + (lane % TILE) + 4 * (lane / TILE) * TILE floats
 template <int NT>
@@ -473,18 +761,6 @@ __device__ __forceinline__ Gate pop_front(Gate (&q)[N]) {
     return m;
 }
 
-#ifdef PN_TRACE_CHAIN  // debug build only (PN_EXTRA=-DPN_TRACE_CHAIN): shader-clock stamps of one wave's second tile
-__device__ unsigned long long g_chain_trace[64];
-extern "C" int pn_chain_trace_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
-}
-#define TR(i)                                                                                          \
-    do {                                                                                               \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && st == (int64_t)gridDim.x) g_chain_trace[i] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define TR(i)
-#endif
 
 // ---------------------------------------------------------------------------------- shared pieces of the chains
 __device__ __forceinline__ float ch_sp_d1(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
@@ -543,6 +819,20 @@ __device__ __forceinline__ float fast_cos(float y) {
     return ((q + 1) & 2) ? -v : v;
 }
 
+// The lane group g = lane / TILE has NG values and hipcc knows it: feature arithmetic written in terms of g is turned into
+// one specialised code path per lane group, executed one after the other under exec masks (the encoding ran 3-4x longer
+// than its instruction count).  An opaque copy keeps it as plain per-lane arithmetic.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// level l = f / 3 and channel ch = f % 3 of encoding feature f (< 96) without an integer division; 2^l
+__device__ __forceinline__ void level_of(int f, int& l, int& ch) {
+    l = (f * 43691) >> 17;
+    ch = f - 3 * l;
+}
+__device__ __forceinline__ float pow2i(int l) { return __int_as_float((127 + l) << 23); }
+
 // per-lane coordinates of a wave's tile
 struct Tile {
     int64_t blk, row, rc;  // sample block, sample row, row clamped into [0, M)
@@ -564,17 +854,18 @@ __device__ __forceinline__ Tile tile_of(int64_t st, int wid, int lane, int64_t M
 // integrated positional encoding (MODE 0), or its tangent along v (MODE 1), of this lane's 96 / NG features -> T-layout
 // store + B operand.  Features f and f + 48 (sine / "cosine" of the same argument) sit in the same lane.
 template <int NP, int MODE>
-__device__ __forceinline__ void encode(const float (&mu)[3], const float (&cv)[3], const float (&vv)[3], int g, float* et,
-                                       BFrag<NP> (&benc)[KS_ENC]) {
+__device__ __forceinline__ Ex encode(const float (&mu)[3], const float (&cv)[3], const float (&vv)[3], int g, float* et,
+                                      BFrag<NP> (&benc)[KS_ENC]) {
     constexpr int NQ = 96 / QB;  // quad blocks of the encoding; the first half are the sines
     float x[NQ][4];
+    const int g4 = 4 * opaque(g);
 #pragma unroll
     for (int qb = 0; qb < NQ / 2; ++qb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = QB * qb + 4 * g + i;  // level l = f / 3, channel f % 3
-            const int l = f / 3, ch = f - 3 * l;
-            const float sc = (float)(1 << l);
+            int l, ch;
+            level_of(QB * qb + g4 + i, l, ch);
+            const float sc = pow2i(l);
             const float y = sel3(mu, ch) * sc;
             const float e0 = __expf(-0.5f * (sel3(cv, ch) * (sc * sc)));
             if constexpr (MODE == 0) {
@@ -586,42 +877,82 @@ __device__ __forceinline__ void encode(const float (&mu)[3], const float (&cv)[3
                 x[qb + NQ / 2][i] = e * fast_cos(y + HALF_PI_F);
             }
         }
+#ifdef PN_TRACE_CHAIN
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(x[qb][i]));
+    if (MODE == 0) TRX(31);
+#endif
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) et[(QB * qb + i) * TILE] = x[qb][i];
+    if (MODE == 0) TRX(32);
+    Ex e{0, 0u};
+    if constexpr (NP == 2) {
+        if constexpr (MODE == 0) {
+            e.ex = EXP_TOP - 1;  // |feature| <= 1
+            e.top = 0x3f800000u;
+        } else {
+            float m = 0.f;
+#pragma unroll
+            for (int qb = 0; qb < NQ; ++qb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(x[qb][i]));
+            e = ex_of(m);
+        }
+    }
 #pragma unroll
     for (int s = 0; s < KS_ENC; ++s) {
         float y8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) y8[j] = x[2 * s + (j >> 2)][j & 3];
-        split_into<NP>(y8, benc[s]);
+        split_into<NP>(y8, benc[s], e.ex);
     }
+    return e;
 }
 // B operand k-steps <- a stored T-layout block of this wave (fp32): the encoding for the skip columns, r5 / delta5
 template <int NP, int KS>
-__device__ __forceinline__ void reload_b(const float* src, BFrag<NP> (&b)[KS]) {
+__device__ __forceinline__ int reload_b(const float* src, BFrag<NP> (&b)[KS]) {
+    if constexpr (NP == 2) {  // all values first: the exponent comes from their maximum
+        float x[KS][8];
+        float m = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        float x[8];
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];  // + 4 g rows via the lane offset
-        split_into<NP>(x, b[ks]);
+            for (int j = 0; j < 8; ++j) {
+                x[ks][j] = src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];
+                m = fmaxf(m, fabsf(x[ks][j]));
+            }
+        const int ex = scale_exp(col_max(m));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) split_into<NP>(x[ks], b[ks], ex);
+        return ex;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];  // + 4 g rows via the lane offset
+            split_into<NP>(x, b[ks]);
+        }
+        return 0;
     }
 }
 // d enc (accumulator tiles over 96 features) -> d mean of this lane's sample; every lane group ends with the sum
 __device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], const float (&mu)[3], const float (&cv)[3], int g,
                                                    float (&dm)[3]) {
     dm[0] = dm[1] = dm[2] = 0.f;
+    const int g4 = 4 * opaque(g);
 #pragma unroll
     for (int qb = 0; qb < 96 / QB; ++qb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int F = QB * qb + 4 * g + i;
-            const bool cosine = F >= 48;
-            const int f = cosine ? F - 48 : F;
-            const int l = f / 3, ch = f - 3 * l;
-            const float sc = (float)(1 << l);
+            const bool cosine = qb >= 96 / QB / 2;  // features 48..95 (QB divides 48)
+            int l, ch;
+            level_of(QB * (cosine ? qb - 96 / QB / 2 : qb) + g4 + i, l, ch);
+            const float sc = pow2i(l);
             const float y = sel3(mu, ch) * sc;
             const float ex = __expf(-0.5f * (sel3(cv, ch) * (sc * sc))) * sc;
             const float d = AQ(acc, qb, i) * ex * fast_cos(cosine ? y + HALF_PI_F : y);
@@ -637,10 +968,10 @@ __device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], co
 }
 // gate, T-layout store and next B operand of a 256-wide hidden vector (backward-direction sweeps and the tangent sweep)
 template <int NP>
-__device__ __forceinline__ void finish_gated(accv (&acc)[NT_H], const Gate& m, float* out, BFrag<NP> (&bh)[KS_H]) {
+__device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, float* out, BFrag<NP> (&bh)[KS_H]) {
     gate_bits<NT_H>(acc, m);
     if (out) store_t<NT_H>(out, acc);  // (wave-uniform)
-    acc_to_b<NP, NT_H, KS_H>(acc, bh);
+    return acc_to_b<NP, NT_H, KS_H>(acc, bh);
 }
 
 // ------------------------------------------------------------------------------------------------- forward chain
@@ -649,6 +980,8 @@ struct FwdArgs {
     int rows_per_ray, nc;
     int64_t view_rows;
     const unsigned char* pack;
+    const int* wexp;       // NP = 2: exponent of every forward-direction GEMM's weights
+    uint32_t* amax;        // NP = 2: this evaluation's table of maxima (AM_COUNT slots) or null
     const float* mean;     // [M,3]
     const float* cov;      // [M,3]
     const float* viewdirs; // [view_rows,3]
@@ -671,6 +1004,8 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
     const int64_t Mp = a.nst * CH_SAMPLES;
     Ring<NP> R;
     R.start(a.pack, lds, fwd_chunk0<NP>(F_COUNT), wid, lane, 0);
+    RunMax<10> RM;  // activation slots 0..9
+    RM.clear();
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         TR(0);
@@ -678,6 +1013,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         BFrag<NP> bh[KS_H];
         accv acc[NT_H];
         Gate mw;
+        int bex = 0;  // NP = 2: exponent of the B operand in flight
+        auto wx = [&](int i) {
+            if constexpr (NP == 2) return a.wexp[i];
+            else return 0;
+        };
         {
             // ---- integrated positional encoding -> B operand of layer 0
             float mu[3], cv[3];
@@ -688,45 +1028,51 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
                 cv[i] = a.cov[T.rc * 3 + i];
             }
             BFrag<NP> benc[KS_ENC];
-            encode<NP, 0>(mu, cv, zero3, T.g, et, benc);
+#ifdef PN_TRACE_CHAIN
+            asm volatile("" ::"v"(mu[0]), "v"(mu[1]), "v"(mu[2]), "v"(cv[0]), "v"(cv[1]), "v"(cv[2]));
+            TRX(30);
+#endif
+            bex = encode<NP, 0>(mu, cv, zero3, T.g, et, benc).ex;
             TR(1);
-            chain_gemm<NP, KS_ENC, NT_H, true, false>(R, benc, acc, lane);
+            chain_gemm<NP, KS_ENC, NT_H, true, false, true>(R, benc, acc, lane, wx(F_L0) + bex);
             TR(2);
         }
         auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T store, next B operand
             relu_bits<NT_H>(acc, mw);
             if (a.acts_t) store_t<NT_H>(a.acts_t + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);  // (uniform)
             store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
-            acc_to_b<NP, NT_H, KS_H>(acc, bh);
+            const Ex e = acc_to_b<NP, NT_H, KS_H>(acc, bh);
+            bex = e.ex;
+            RM.upd(slot, e.top);
         };
         finish_hidden(0);
         TR(3);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
-            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_L0 + l) + bex);
             TR(2 + 2 * l);
             finish_hidden(l);
             TR(3 + 2 * l);
         }
         {  // ---- layer 5: [h4 | enc] as two accumulating GEMMs (F_L5, F_L5E)
-            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_L5) + bex);
             BFrag<NP> benc[KS_ENC];
-            reload_b<NP, KS_ENC>(et, benc);
-            chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane);
+            const int eex = reload_b<NP, KS_ENC>(et, benc);
+            chain_gemm<NP, KS_ENC, NT_H, false, false, true>(R, benc, acc, lane, wx(F_L5E) + eex);
             TR(12);
             finish_hidden(5);
             TR(13);
         }
 #pragma unroll 1
         for (int l = 6; l <= 7; ++l) {
-            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_L6 + l - 6) + bex);
             TR(2 + 2 * l);
             finish_hidden(l);
             TR(3 + 2 * l);
         }
         {  // ---- density head (one tile; channel ch is feature ch: quad block 0 of lane group ch / 4)
             accv ad[1];
-            chain_gemm<NP, KS_H, 1, true, false>(R, bh, ad, lane);
+            chain_gemm<NP, KS_H, 1, true, false, true>(R, bh, ad, lane, wx(F_DEN) + bex);
             if (T.live) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -738,52 +1084,58 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         TR(18);
         // ---- bottleneck (no activation), then the view layer over [bottleneck | view encoding]
         BFrag<NP> bv[KS_H + KS_PAD];
+        int vex;
         {
-            chain_gemm<NP, KS_H, NT_H, true, false>(R, bh, acc, lane);
+            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_EXTRA) + bex);
             TR(19);
             float* bt = a.acts_t ? a.acts_t + act_off(8, Mp) + T.blk * (288 * TILE) + T.lo : nullptr;
             if (bt) store_t<NT_H>(bt, acc);
-            acc_to_b<NP, NT_H, KS_H + KS_PAD>(acc, bv);
+            const Ex e = acc_to_b<NP, NT_H, KS_H + KS_PAD>(acc, bv, 1.0f);  // the view encoding appended below is <= 1
+            vex = e.ex;
+            RM.upd(8, e.top);
             const int64_t vr = (T.rc / a.rows_per_ray) % a.view_rows;
             float vd[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) vd[i] = a.viewdirs[vr * 3 + i];
+            const int g4 = 4 * opaque(T.g);
 #pragma unroll
             for (int q = 0; q < KS_PAD; ++q) {
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int v = QB * (2 * q + (j >> 2)) + 4 * T.g + (j & 3);  // view-encoding feature 0..31 (27 real)
-                    float o = 0.f;
-                    if (v < 3) {
-                        o = sel3(vd, v);
-                    } else if (v < PN_VIEW_DIM) {
-                        const int i = v - 3, f = i % 12, half = i / 12, l = f / 3, ch = f % 3;
-                        const float xb = sel3(vd, ch) * (float)(1 << l);
-                        o = fast_sin(half ? xb + HALF_PI_F : xb);
-                    }
+                    const int v = QB * (2 * q + (j >> 2)) + g4 + (j & 3);  // view-encoding feature 0..31 (27 real)
+                    // features 3..26: sin(x 2^l) for l < 4, then sin(x 2^l + pi/2); branch-free (see opaque())
+                    const int i = v - 3, half = i >= 12 ? 1 : 0;
+                    int l, ch;
+                    level_of(i < 0 ? 0 : i - 12 * half, l, ch);
+                    const float xb = sel3(vd, ch) * pow2i(l & 3);
+                    const float sv = fast_sin(half ? xb + HALF_PI_F : xb);
+                    const float o = v < 3 ? sel3(vd, v) : (v < PN_VIEW_DIM ? sv : 0.f);
                     x[j] = o;
                     if (bt) bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = o;
                 }
-                split_into<NP>(x, bv[KS_H + q]);
+                split_into<NP>(x, bv[KS_H + q], vex);
             }
         }
         TR(20);
         BFrag<NP> bc[KS_C];
+        int cex;
         {
             accv av[NT_C];
-            chain_gemm<NP, KS_H + KS_PAD, NT_C, true, false>(R, bv, av, lane);
+            chain_gemm<NP, KS_H + KS_PAD, NT_C, true, false, true>(R, bv, av, lane, wx(F_VIEW) + vex);
             TR(21);
             Gate w4;
             relu_bits<NT_C>(av, w4);
             if (a.acts_t) store_t<NT_C>(a.acts_t + act_off(9, Mp) + T.blk * (128 * TILE) + T.lo, av);
             store_gate(a.masks, 8, Mp, T.blk * TILE + T.c, T.g, w4);
-            acc_to_b<NP, NT_C, KS_C>(av, bc);
+            const Ex e = acc_to_b<NP, NT_C, KS_C>(av, bc);
+            cex = e.ex;
+            RM.upd(9, e.top);
         }
         TR(22);
         {
             accv ac[1];
-            chain_gemm<NP, KS_C, 1, true, false>(R, bc, ac, lane);
+            chain_gemm<NP, KS_C, 1, true, false, true>(R, bc, ac, lane, wx(F_COLOR) + cex);
             TR(23);
             if (T.live && T.g == 0) {
 #pragma unroll
@@ -793,6 +1145,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         TR(24);
     }
     R.drain();
+    if constexpr (NP == 2) {
+        RM.flush(a.amax ? a.amax + AM_ACT0 : nullptr, lane);
+        if (a.amax && blockIdx.x == 0 && tid == 0) a.amax[AM_ENC] = 0x3f800000u;  // |encoding| <= 1
+    }
 }
 
 // ------------------------------------------------------------------------- density-gradient reverse sweep (level 1)
@@ -805,6 +1161,8 @@ struct SweepArgs {
     float density_bias;
     const unsigned char* pack;   // first chunk of the sub-chain this kernel walks
     int nchunk;
+    const int* wexp;             // NP = 2: weight exponents of the direction this kernel walks (indexed F_* / B_*)
+    uint32_t* amax;              // NP = 2: this evaluation's table of maxima or null
     const uint32_t* masks;       // [9][Mp][8]
     const float* raw_den;        // [M,nc]
     const float* mean;
@@ -826,6 +1184,8 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
     const int64_t Mp = a.nst * CH_SAMPLES;
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
+    RunMax<8> RM;  // r_0..r_7
+    RM.clear();
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         Gate mk[8];  // gates of h7, h6, ..., h0
@@ -839,9 +1199,25 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         }
         const float sgm = T.live ? ch_sp_d1(a.raw_den[T.rc * a.nc] + a.density_bias) : 0.f;
         BFrag<NP> bh[KS_H];
+        int bex = 0;
+        auto wx = [&](int i) {
+            if constexpr (NP == 2) return a.wexp[i];
+            else return 0;
+        };
         {  // seed r_7
             float* rt = a.keep_all ? a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo : nullptr;
             const Gate m7 = pop_front(mk);
+            if constexpr (NP == 2) {  // |r_7| <= softplus'(z) * max |Wd[0]| over this lane's features
+                float wm = 0.f;
+#pragma unroll
+                for (int qb = 0; qb < NT_H * ACCQ; ++qb) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.wd0 + QB * qb + 4 * T.g);
+                    wm = fmaxf(fmaxf(wm, fmaxf(fabsf(wv[0]), fabsf(wv[1]))), fmaxf(fabsf(wv[2]), fabsf(wv[3])));
+                }
+                const Ex e = ex_of(sgm * wm);
+                bex = e.ex;
+                RM.upd(7, e.top);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS_H; ++ks) {
                 float x[8];
@@ -856,21 +1232,23 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
                         if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = x[j];
                     }
                 }
-                split_into<NP>(x, bh[ks]);
+                split_into<NP>(x, bh[ks], bex);
             }
         }
         accv acc[NT_H];
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
-            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
             float* dst = a.keep_all ? a.vec_t + (int64_t)(l - 1) * Mp * 256 : (l - 1 == 5 ? a.vec_t : nullptr);
-            finish_gated<NP>(acc, pop_front(mk), dst ? dst + T.blk * (256 * TILE) + T.lo : nullptr, bh);
+            const Ex e = finish_gated<NP>(acc, pop_front(mk), dst ? dst + T.blk * (256 * TILE) + T.lo : nullptr, bh);
+            bex = e.ex;
+            RM.upd(l - 1, e.top);
         }
         {  // d sigma / d enc over [r_0 | r_5] (two accumulating GEMMs: B_DENC0, B_DENC1), then the encoding's adjoint
             accv a3[NT_ENC];
-            chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane);
-            reload_b<NP, KS_H>(a.vec_t + (a.keep_all ? (int64_t)5 * Mp * 256 : 0) + T.blk * (256 * TILE) + T.lo, bh);
-            chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane);
+            chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane, wx(B_DENC0) + bex);
+            bex = reload_b<NP, KS_H>(a.vec_t + (a.keep_all ? (int64_t)5 * Mp * 256 : 0) + T.blk * (256 * TILE) + T.lo, bh);
+            chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane, wx(B_DENC1) + bex);
             float dm[3];
             ipe_backward_tiles(a3, mu, cv, T.g, dm);
             if (T.live && T.g == 0) {
@@ -881,6 +1259,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         }
     }
     R.drain();
+    if constexpr (NP == 2) RM.flush(a.amax ? a.amax + AM_RS0 : nullptr, lane);
 }
 
 // ------------------------------------------------------------------------------------- tangent sweep (level 1)
@@ -894,6 +1273,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
     const int64_t Mp = a.nst * CH_SAMPLES;
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
+    RunMax<9> RM;  // hdot_0..hdot_7, edot
+    RM.clear();
+    Ex e;
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         Gate mk[8];
@@ -902,6 +1284,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
         float* et = a.edot_t + T.blk * (96 * TILE) + T.lo;
         BFrag<NP> bh[KS_H];
         accv acc[NT_H];
+        int bex = 0;
+        auto wx = [&](int i) {
+            if constexpr (NP == 2) return a.wexp[i];
+            else return 0;
+        };
         {
             float mu[3], cv[3], vv[3];
 #pragma unroll
@@ -911,28 +1298,39 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
                 vv[i] = T.live ? a.v[T.rc * 3 + i] : 0.f;
             }
             BFrag<NP> benc[KS_ENC];
-            encode<NP, 1>(mu, cv, vv, T.g, et, benc);
-            chain_gemm<NP, KS_ENC, NT_H, false, true>(R, benc, acc, lane);
+            e = encode<NP, 1>(mu, cv, vv, T.g, et, benc);
+            bex = e.ex;
+            RM.upd(8, e.top);
+            chain_gemm<NP, KS_ENC, NT_H, false, true>(R, benc, acc, lane, wx(F_L0) + bex);
         }
-        finish_gated<NP>(acc, pop_front(mk), a.vec_t + T.blk * (256 * TILE) + T.lo, bh);
+        e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + T.blk * (256 * TILE) + T.lo, bh);
+        bex = e.ex;
+        RM.upd(0, e.top);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
-            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)l * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L0 + l) + bex);
+            e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)l * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            bex = e.ex;
+            RM.upd(l, e.top);
         }
         {
-            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L5) + bex);
             BFrag<NP> benc[KS_ENC];
-            reload_b<NP, KS_ENC>(et, benc);
-            chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            const int eex = reload_b<NP, KS_ENC>(et, benc);
+            chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane, wx(F_L5E) + eex);
+            e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            bex = e.ex;
+            RM.upd(5, e.top);
         }
-        chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
-        finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)6 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
-        chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
+        chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L6) + bex);
+        e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)6 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        bex = e.ex;
+        RM.upd(6, e.top);
+        chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L7) + bex);
         {
             gate_bits<NT_H>(acc, pop_front(mk));
             store_t<NT_H>(a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, acc);
+            if constexpr (NP == 2) RM.upd(7, ex_of(lane_amax<NT_H>(acc)).top);
             float sd = 0.f;
 #pragma unroll
             for (int qb = 0; qb < NT_H * ACCQ; ++qb) {
@@ -946,6 +1344,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
         }
     }
     R.drain();
+    if constexpr (NP == 2) RM.flush(a.amax ? a.amax + AM_TANG0 : nullptr, lane);
 }
 
 // ------------------------------------------------------------------------------------------------- backward chain
@@ -956,6 +1355,8 @@ struct BwdArgs {
     float density_bias;
     const unsigned char* pack;  // backward chain
     int nchunk;                 // chunks walked per tile (with or without the d enc GEMM)
+    const int* wexp;            // NP = 2: weight exponents of the backward-direction GEMMs (indexed B_*)
+    uint32_t* amax;             // NP = 2: this evaluation's table of maxima or null
     const uint32_t* masks;
     const float* raw_den;       // [M,nc]
     const float* d_rgb;         // [M,3]
@@ -979,6 +1380,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
     const int64_t Mp = a.nst * CH_SAMPLES;
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
+    RunMax<12> RM;  // delta_0..7, d bottleneck, d raw_density, d view hidden, d rgb
+    RM.clear();
+    Ex e;
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         Gate mk[9];  // gates of the view hidden, h7, h6, ..., h0
@@ -986,36 +1390,50 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
         for (int l = 0; l < 9; ++l) mk[l] = load_gate(a.masks, 8 - l, Mp, T.blk * TILE + T.c, T.g);
         // ---- colour head: d hv = gate * (Wc^T d rgb); the k-step holds KSTEP features, 3 real (lane group 0)
         BFrag<NP> b1[1];
+        int bex = 0;
+        auto wx = [&](int i) {
+            if constexpr (NP == 2) return a.wexp[i];
+            else return 0;
+        };
         {
             float x[8];
             float* dt = a.drgb_t + T.blk * (32 * TILE) + T.lo;
+            float m = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int f = QB * (j >> 2) + 4 * T.g + (j & 3);
                 x[j] = (T.live && f < 3) ? a.d_rgb[T.rc * 3 + (f < 3 ? f : 0)] : 0.f;
                 dt[(QB * (j >> 2) + (j & 3)) * TILE] = x[j];
+                m = fmaxf(m, fabsf(x[j]));
             }
-            split_into<NP>(x, b1[0]);
+            if constexpr (NP == 2) {
+                e = ex_of(m);
+                bex = e.ex;
+                RM.upd(11, e.top);
+            }
+            split_into<NP>(x, b1[0], bex);
         }
         BFrag<NP> bc[KS_C];
         {
             accv av[NT_C];
-            chain_gemm<NP, 1, NT_C, false, true>(R, b1, av, lane);
+            chain_gemm<NP, 1, NT_C, false, true>(R, b1, av, lane, wx(B_COLOR) + bex);
             gate_bits<NT_C>(av, pop_front(mk));
             store_t<NT_C>(a.dhv_t + T.blk * (128 * TILE) + T.lo, av);
-            acc_to_b<NP, NT_C, KS_C>(av, bc);
+            e = acc_to_b<NP, NT_C, KS_C>(av, bc);
+            bex = e.ex;
+            RM.upd(10, e.top);
         }
         // ---- view layer: d bottleneck = Wv[:, :256]^T d hv ; then [d bottleneck | d raw_density] through [We ; Wd]^T
         BFrag<NP> be[KS_H + 1];
         accv acc[NT_H];
         {
-            chain_gemm<NP, KS_C, NT_H, false, true>(R, bc, acc, lane);
+            chain_gemm<NP, KS_C, NT_H, false, true>(R, bc, acc, lane, wx(B_VIEW) + bex);
             float* bt = a.d8_t + T.blk * (288 * TILE) + T.lo;
             store_t<NT_H>(bt, acc);
-            acc_to_b<NP, NT_H, KS_H + 1>(acc, be);
             const float z = a.raw_den[T.rc * a.nc] + a.density_bias;
             const float add0 = (a.sdot && T.live) ? ch_sp_d2(z) * a.sdot[T.rc] : 0.f;
             float x[8];
+            float m = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ch = QB * (j >> 2) + 4 * T.g + (j & 3);
@@ -1023,8 +1441,17 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
                 if (T.live && ch < a.nc) v = a.d_den[T.rc * a.nc + ch] + (ch == 0 ? add0 : 0.f);
                 x[j] = v;
                 bt[(256 + QB * (j >> 2) + (j & 3)) * TILE] = v;
+                m = fmaxf(m, fabsf(v));
             }
-            split_into<NP>(x, be[KS_H]);
+            if constexpr (NP == 2) {  // one exponent for the whole operand, separate maxima for the two T tensors
+                e = ex_of(lane_amax<NT_H>(acc));
+                const Ex ed = ex_of(m);
+                RM.upd(8, e.top);
+                RM.upd(9, ed.top);
+                bex = e.ex < ed.ex ? e.ex : ed.ex;
+            }
+            split_acc<NP, NT_H, KS_H + 1>(acc, be, bex);
+            split_into<NP>(x, be[KS_H], bex);
             if (a.coef_t) {
                 float* ct = a.coef_t + T.blk * (32 * TILE) + T.lo;
                 const float cf = T.live ? ch_sp_d1(z) : 0.f;
@@ -1036,12 +1463,16 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
             }
         }
         BFrag<NP> bh[KS_H];
-        chain_gemm<NP, KS_H + 1, NT_H, false, true>(R, be, acc, lane);
-        finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        chain_gemm<NP, KS_H + 1, NT_H, false, true>(R, be, acc, lane, wx(B_EXTRA) + bex);
+        e = finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        bex = e.ex;
+        RM.upd(7, e.top);
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
-            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane);
-            finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
+            e = finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            bex = e.ex;
+            RM.upd(l - 1, e.top);
         }
         if (a.d_mean) {  // uniform: d enc over [delta_0 | delta_5], then the encoding's adjoint
             float mu[3], cv[3];
@@ -1051,9 +1482,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
                 cv[i] = a.cov[T.rc * 3 + i];
             }
             accv a3[NT_ENC];
-            chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane);
-            reload_b<NP, KS_H>(a.delta_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
-            chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane);
+            chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane, wx(B_DENC0) + bex);
+            bex = reload_b<NP, KS_H>(a.delta_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane, wx(B_DENC1) + bex);
             float dm[3];
             ipe_backward_tiles(a3, mu, cv, T.g, dm);
             if (T.live && T.g == 0) {
@@ -1064,6 +1495,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
         }
     }
     R.drain();
+    if constexpr (NP == 2) {
+        RM.flush(a.amax ? a.amax + AM_DELTA0 : nullptr, lane);
+        if (a.amax && blockIdx.x == 0 && tid == 0) a.amax[AM_COEF] = 0x3f800000u;  // softplus' <= 1
+    }
 }
 
 // ------------------------------------------------------------------------------------- weight gradients (TN GEMM)
@@ -1080,6 +1515,8 @@ struct WSeg {
     int64_t nhalf;   // 16-sample half blocks
     int FX, FY;      // features per block of the tensors X / Y live in
     int bias;        // rows of this segment count towards the row sums of X (the second-order rows do not)
+    const uint32_t* ax;  // NP = 2: largest |x| of the whole X / Y tensor (float bits, written by the chain kernels): the
+    const uint32_t* ay;  // segment's operands are scaled by ONE power of two each (the sum runs over all samples)
 };
 struct WgArgs {
     WSeg seg[4];
@@ -1099,6 +1536,10 @@ __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<N
         v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], v, 0, 0, 0);
         v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], v, 0, 0, 0);
         v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
+    } else if constexpr (NP == 2) {
+        v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[1], b.p[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[0], b.p[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[0], b.p[0], v, 0, 0, 0);
     } else {
         v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], v, 0, 0, 0);
     }
@@ -1134,6 +1575,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     // blocks of MFMA time to land (one workgroup per CU: nothing else hides the HBM latency)
     f32x4 xr[2][LX], yr[2][LY];
     float bw[2] = {0.f, 0.f};  // bias weight of the half block held in each set
+    // NP = 2: exponents of the half block held in each register set, unit (sum of both) of each LDS buffer and of the
+    // accumulators: a workgroup whose range crosses into a segment with other scales re-bases its accumulators (exact)
+    int sx[2] = {0, 0}, sy[2] = {0, 0}, ubuf[2] = {0, 0}, unit = 0;
+    bool first = true;
     auto load = [&](int64_t h, int set) {
         int sg = 0;
         int64_t hb = h;
@@ -1145,6 +1590,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             }
         const WSeg& S = a.seg[sg];
         bw[set] = S.bias ? 1.f : 0.f;
+        if constexpr (NP == 2) {
+            sx[set] = scale_exp(__uint_as_float(*S.ax));
+            sy[set] = scale_exp(__uint_as_float(*S.ay));
+        }
         const int64_t blk = hb / (TILE / 16);  // a T-layout sample block holds TILE / 16 half blocks
         const int half = (int)(hb % (TILE / 16));
         const float* xb = S.X + blk * ((int64_t)S.FX * TILE) + half * 16;
@@ -1160,26 +1609,40 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             if (CY % NTH == 0 || idx < CY) yr[set][i] = *reinterpret_cast<const f32x4*>(yb + (idx >> 2) * TILE + (idx & 3) * 4);
         }
     };
-    auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v) {
+    auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v, int ex) {
         const int f = idx >> 2, q = idx & 3;
         const int o = f * 16 + (((q >> 1) ^ ((f >> 3) & 1)) << 3) + (q & 1) * 4;
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        bf16x4 hv, mv, lv;
+        if constexpr (NP == 2) {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 hv, lv;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const __bf16 hb = (__bf16)v[c];
-            hv[c] = hb;
-            if constexpr (NP == 3) {
-                const float r1 = v[c] - (float)hb;
-                const __bf16 mb = (__bf16)r1;
-                mv[c] = mb;
-                lv[c] = (__bf16)(r1 - (float)mb);
+            for (int c = 0; c < 4; ++c) {
+                const float t = ldexpf(v[c], ex);
+                const _Float16 hh = (_Float16)t;
+                hv[c] = hh;
+                lv[c] = (_Float16)(t - (float)hh);
             }
-        }
-        *reinterpret_cast<bf16x4*>(plane0 + o) = hv;
-        if constexpr (NP == 3) {
-            *reinterpret_cast<bf16x4*>(plane0 + pstride + o) = mv;
-            *reinterpret_cast<bf16x4*>(plane0 + 2 * pstride + o) = lv;
+            *reinterpret_cast<f16x4*>(plane0 + o) = hv;
+            *reinterpret_cast<f16x4*>(plane0 + pstride + o) = lv;
+        } else {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 hv, mv, lv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const __bf16 hb = (__bf16)v[c];
+                hv[c] = hb;
+                if constexpr (NP == 3) {
+                    const float r1 = v[c] - (float)hb;
+                    const __bf16 mb = (__bf16)r1;
+                    mv[c] = mb;
+                    lv[c] = (__bf16)(r1 - (float)mb);
+                }
+            }
+            *reinterpret_cast<bf16x4*>(plane0 + o) = hv;
+            if constexpr (NP == 3) {
+                *reinterpret_cast<bf16x4*>(plane0 + pstride + o) = mv;
+                *reinterpret_cast<bf16x4*>(plane0 + 2 * pstride + o) = lv;
+            }
         }
     };
     auto stage = [&](int buf, int set) {
@@ -1189,23 +1652,42 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
             if (CX % NTH == 0 || idx < CX) {
-                put(xs, PX, idx, xr[set][i]);
+                put(xs, PX, idx, xr[set][i], sx[set]);
                 bsum[i] += bw[set] * ((xr[set][i][0] + xr[set][i][1]) + (xr[set][i][2] + xr[set][i][3]));
             }
         }
 #pragma unroll
         for (int i = 0; i < LY; ++i) {
             const int idx = tid + NTH * i;
-            if (CY % NTH == 0 || idx < CY) put(ys, PY, idx, yr[set][i]);
+            if (CY % NTH == 0 || idx < CY) put(ys, PY, idx, yr[set][i], sy[set]);
         }
+        ubuf[buf] = sx[set] + sy[set];
     };
     const int fr = lane & 31, fh = lane >> 5;
     auto frag = [&](const unsigned short* plane, int feature) {
-        return *reinterpret_cast<const bf16x8*>(plane + feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3));
+        return *reinterpret_cast<const typename PlaneOf<NP>::type*>(plane + feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3));
     };
     auto compute = [&](int buf) {
         const unsigned short* xs = smem + buf * BUF;
         const unsigned short* ys = xs + NP * PX;
+        if constexpr (NP == 2) {
+            if (first) {
+                unit = ubuf[buf];
+                first = false;
+            } else if (ubuf[buf] != unit) {  // (uniform, at most once per segment boundary)
+                const int d = ubuf[buf] - unit;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float x = acc[i][j][e];
+                            acc[i][j][e] = ldexpf(x, d);
+                        }
+                unit = ubuf[buf];
+            }
+        }
         BFrag<NP> af[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1244,7 +1726,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = 32 * (wm * TM + i) + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                out[(int64_t)row * TNW + 32 * (wn * TN + j) + fr] = acc[i][j][e];
+                const float x = acc[i][j][e];
+                out[(int64_t)row * TNW + 32 * (wn * TN + j) + fr] = NP == 2 ? ldexpf(x, -unit) : x;
             }
     if (a.bias) {
 #pragma unroll
@@ -1341,18 +1824,29 @@ static PackTable bwd_table(int nc) {
     return T;
 }
 
+// the packed blob: [forward chain | backward chain | int wexp[F_COUNT + B_COUNT] (NP = 2; 256 bytes)]
 template <int NP>
-static int pack_chain(const PackTable& T, const float* params, unsigned char* out, hipStream_t s) {
+static constexpr int64_t chain_bytes() { return (int64_t)(fwd_chunk0<NP>(F_COUNT) + bwd_chunk0<NP>(B_COUNT)) * Cfg<NP>::SLOT; }
+constexpr int64_t WEXP_BYTES = 256;
+static_assert((F_COUNT + B_COUNT) * 4 <= WEXP_BYTES, "wexp table");
+template <int NP>
+static int pack_chain(const PackTable& T, const float* params, unsigned char* out, int* wexp, hipStream_t s) {
+    if (NP == 2) {
+        hipLaunchKernelGGL(k_chain_wexp, dim3(T.n), dim3(256), 0, s, T, params, wexp);
+        PN_CHECK_LAUNCH();
+    }
     const int64_t threads = (int64_t)T.nchunks * (Cfg<NP>::CF + 1) * 64;
-    hipLaunchKernelGGL(k_chain_pack<NP>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, T, params, out);
+    hipLaunchKernelGGL(k_chain_pack<NP>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, T, params, out, wexp);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
 template <int NP>
 static int pack_both(int nc, const float* params, unsigned char* out, hipStream_t s) {
-    int rc = pack_chain<NP>(fwd_table<NP>(nc), params, out, s);
+    int* wexp = reinterpret_cast<int*>(out + chain_bytes<NP>());
+    if (NP != 2 && hipMemsetAsync(wexp, 0, WEXP_BYTES, s) != hipSuccess) return PN_ERR_HIP;  // (unused: keep the blob defined)
+    int rc = pack_chain<NP>(fwd_table<NP>(nc), params, out, wexp, s);
     if (rc != PN_OK) return rc;
-    return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, s);
+    return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, wexp + F_COUNT, s);
 }
 
 template <typename K, typename A>
@@ -1367,7 +1861,10 @@ static int chain_grid(int64_t nst) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) g_chain_cus = 256;
         else g_chain_cus = pr.multiProcessorCount;
     }
-    const int64_t wgs = (int64_t)g_chain_cus * CH_WG_PER_CU;
+    int64_t wgs = (int64_t)g_chain_cus * CH_WG_PER_CU;
+#ifdef PN_TRACE_CHAIN  // diagnostic: PN_TRACE_ONE_WG=1 leaves every SIMD with ONE wave (is a GEMM phase slowed by its neighbour?)
+    if (getenv("PN_TRACE_ONE_WG")) wgs = g_chain_cus;
+#endif
     return (int)(nst < wgs ? nst : wgs);
 }
 static int chain_cus() {
@@ -1389,11 +1886,29 @@ static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, c
 }
 #define LAUNCH_CHAIN(KERNEL, planes, nst, args, s, cls, flops)                                                   \
     do {                                                                                                        \
-        static bool done3 = false, done1 = false;                                                               \
+        static bool done3 = false, done2 = false, done1 = false;                                                \
         if ((planes) == 3) return launch_chain(KERNEL<3>, Cfg<3>::LDS_BYTES, done3, nst, args, s, cls, flops);  \
+        if ((planes) == 2) return launch_chain(KERNEL<2>, Cfg<2>::LDS_BYTES, done2, nst, args, s, cls, flops);  \
         if ((planes) == 1) return launch_chain(KERNEL<1>, Cfg<1>::LDS_BYTES, done1, nst, args, s, cls, flops);  \
         return PN_ERR_UNSUPPORTED;                                                                              \
     } while (0)
+// where the pieces of a packed blob are, per arithmetic mode
+struct ChainGeom {
+    int64_t slot, bytes;                      // bytes per chunk; bytes of both chains (the wexp table follows)
+    int f_all, f_den, b_all, b_l7, b_denc0;   // chunk counts / first chunks
+};
+template <int NP>
+static ChainGeom geom_of() {
+    return ChainGeom{Cfg<NP>::SLOT, chain_bytes<NP>(), fwd_chunk0<NP>(F_COUNT), fwd_chunk0<NP>(F_DEN),
+                     bwd_chunk0<NP>(B_COUNT), bwd_chunk0<NP>(B_L7), bwd_chunk0<NP>(B_DENC0)};
+}
+static bool chain_geom(int planes, ChainGeom& g) {
+    if (planes == 3) g = geom_of<3>();
+    else if (planes == 2) g = geom_of<2>();
+    else if (planes == 1) g = geom_of<1>();
+    else return false;
+    return true;
+}
 // algorithmic MACs x 2 per sample row: forward / data-gradient chain, and the trunk-only sweeps
 static double flops_mlp(int nc) { return 2.0 * ((nc == 5 ? 611328.0 : 610304.0)); }
 static const double kFlopsSweep = 1016320.0;
@@ -1461,9 +1976,9 @@ int pn_chain_tile(void) { return TILE; }
 
 // bytes of the packed chains for `planes` (3: exact split, 1: plain bf16): [forward chain | backward chain]
 int64_t pn_chain_pack_bytes(int planes) {
-    if (planes == 3) return (int64_t)(fwd_chunk0<3>(F_COUNT) + bwd_chunk0<3>(B_COUNT)) * Cfg<3>::SLOT;
-    if (planes == 1) return (int64_t)(fwd_chunk0<1>(F_COUNT) + bwd_chunk0<1>(B_COUNT)) * Cfg<1>::SLOT;
-    return PN_ERR_UNSUPPORTED;
+    ChainGeom g;
+    if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
+    return g.bytes + WEXP_BYTES;
 }
 
 int pn_chain_pack(const float* params, int nc, int planes, void* pack, void* stream) {
@@ -1472,15 +1987,18 @@ int pn_chain_pack(const float* params, int nc, int planes, void* pack, void* str
     hipStream_t s = (hipStream_t)stream;
     unsigned char* out = (unsigned char*)pack;
     if (planes == 3) return pack_both<3>(nc, params, out, s);
+    if (planes == 2) return pack_both<2>(nc, params, out, s);
     if (planes == 1) return pack_both<1>(nc, params, out, s);
     return PN_ERR_UNSUPPORTED;
 }
 
 int64_t pn_chain_acts_floats(int64_t M) { return acts_floats(pn_pad(M)); }
 
+int pn_chain_amax_slots(void) { return AM_COUNT; }
+
 int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int planes, const void* pack,
                      const float* mean, const float* cov, const float* viewdirs, float* enc_t, float* acts_t,
-                     uint32_t* masks, float* raw_rgb, float* raw_den, void* stream) {
+                     uint32_t* masks, float* raw_rgb, float* raw_den, uint32_t* amax, void* stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     if (!pack || !mean || !cov || !viewdirs || !enc_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;  // acts_t may be null
@@ -1490,9 +2008,14 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     a.rows_per_ray = rows_per_ray;
     a.nc = nc;
     a.view_rows = view_rows;
+    ChainGeom g;
+    if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
     a.pack = (const unsigned char*)pack;
+    a.wexp = reinterpret_cast<const int*>(a.pack + g.bytes);
     a.mean = mean; a.cov = cov; a.viewdirs = viewdirs;
     a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
+    a.amax = planes == 2 ? amax : nullptr;
+    if (a.amax && hipMemsetAsync(a.amax, 0, AM_COUNT * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return PN_ERR_HIP;
     LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, a, (hipStream_t)stream, 2, (double)M * flops_mlp(nc));
 }
 
@@ -1500,45 +2023,47 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
  * weight gradients); grad_mean [M,3] = + d sigma / d mean. */
 int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, const float* params, const void* pack,
                           const float* mean, const float* cov, const uint32_t* masks, const float* raw_den, float* rs_t,
-                          int keep_all, float* grad_mean, void* stream) {
+                          int keep_all, float* grad_mean, uint32_t* amax, void* stream) {
     if (M <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    ChainGeom g;
+    if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
     if (!params || !pack || !mean || !cov || !masks || !raw_den || !rs_t || !grad_mean) return PN_ERR_NULL;
     SweepArgs a{};
     a.M = M;
     a.nst = pn_pad(M) / CH_SAMPLES;
     a.nc = nc;
     a.density_bias = density_bias;
-    const int64_t slot = planes == 3 ? Cfg<3>::SLOT : Cfg<1>::SLOT;
-    const int f_all = planes == 3 ? fwd_chunk0<3>(F_COUNT) : fwd_chunk0<1>(F_COUNT);
-    const int b7 = planes == 3 ? bwd_chunk0<3>(B_L7) : bwd_chunk0<1>(B_L7);
-    const int ball = planes == 3 ? bwd_chunk0<3>(B_COUNT) : bwd_chunk0<1>(B_COUNT);
-    a.pack = (const unsigned char*)pack + (int64_t)(f_all + b7) * slot;
-    a.nchunk = ball - b7;
+    a.pack = (const unsigned char*)pack + (int64_t)(g.f_all + g.b_l7) * g.slot;
+    a.nchunk = g.b_all - g.b_l7;
+    a.wexp = reinterpret_cast<const int*>((const unsigned char*)pack + g.bytes) + F_COUNT;
     a.masks = masks; a.raw_den = raw_den; a.mean = mean; a.cov = cov;
     a.wd0 = params + pn_layout(nc).wd;
     a.vec_t = rs_t; a.out3 = grad_mean; a.keep_all = keep_all != 0;
+    a.amax = planes == 2 ? amax : nullptr;
     LAUNCH_CHAIN(k_chain_dgrad, planes, a.nst, a, (hipStream_t)stream, 3, (double)M * kFlopsSweep);
 }
 
 /* forward-mode tangent sweep along v (see k_chain_tangent): edot_t T32 [Mp*96], tang_t T32 [8][Mp*256], sdot [M]. */
 int pn_chain_tangent(int64_t M, int nc, int planes, const float* params, const void* pack, const float* mean,
                      const float* cov, const uint32_t* masks, const float* v, float* edot_t, float* tang_t, float* sdot,
-                     void* stream) {
+                     uint32_t* amax, void* stream) {
     if (M <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    ChainGeom g;
+    if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
     if (!params || !pack || !mean || !cov || !masks || !v || !edot_t || !tang_t || !sdot) return PN_ERR_NULL;
     SweepArgs a{};
     a.M = M;
     a.nst = pn_pad(M) / CH_SAMPLES;
     a.nc = nc;
     a.pack = (const unsigned char*)pack;
-    a.nchunk = planes == 3 ? fwd_chunk0<3>(F_DEN) : fwd_chunk0<1>(F_DEN);
+    a.nchunk = g.f_den;
+    a.wexp = reinterpret_cast<const int*>((const unsigned char*)pack + g.bytes);
     a.masks = masks; a.mean = mean; a.cov = cov; a.v = v;
     a.wd0 = params + pn_layout(nc).wd;
     a.vec_t = tang_t; a.edot_t = edot_t; a.sdot = sdot;
+    a.amax = planes == 2 ? amax : nullptr;
     LAUNCH_CHAIN(k_chain_tangent, planes, a.nst, a, (hipStream_t)stream, 4, (double)M * kFlopsSweep);
 }
 
@@ -1546,10 +2071,11 @@ int pn_chain_tangent(int64_t M, int nc, int planes, const float* params, const v
 int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const void* pack, const uint32_t* masks,
                       const float* raw_den, const float* d_raw_rgb, const float* d_raw_den, const float* sdot,
                       const float* mean, const float* cov, float* drgb_t, float* dhv_t, float* d8_t, float* delta_t,
-                      float* coef_t, float* d_mean, void* stream) {
+                      float* coef_t, float* d_mean, uint32_t* amax, void* stream) {
     if (M <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    ChainGeom g;
+    if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
     if (!pack || !masks || !raw_den || !d_raw_rgb || !d_raw_den || !drgb_t || !dhv_t || !d8_t || !delta_t) return PN_ERR_NULL;
     if (d_mean && (!mean || !cov)) return PN_ERR_NULL;
     if ((sdot == nullptr) != (coef_t == nullptr)) return PN_ERR_NULL;
@@ -1558,14 +2084,13 @@ int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const v
     a.nst = pn_pad(M) / CH_SAMPLES;
     a.nc = nc;
     a.density_bias = density_bias;
-    const int64_t slot = planes == 3 ? Cfg<3>::SLOT : Cfg<1>::SLOT;
-    const int f_all = planes == 3 ? fwd_chunk0<3>(F_COUNT) : fwd_chunk0<1>(F_COUNT);
-    a.pack = (const unsigned char*)pack + (int64_t)f_all * slot;
-    a.nchunk = d_mean ? (planes == 3 ? bwd_chunk0<3>(B_COUNT) : bwd_chunk0<1>(B_COUNT))
-                      : (planes == 3 ? bwd_chunk0<3>(B_DENC0) : bwd_chunk0<1>(B_DENC0));
+    a.pack = (const unsigned char*)pack + (int64_t)g.f_all * g.slot;
+    a.nchunk = d_mean ? g.b_all : g.b_denc0;
+    a.wexp = reinterpret_cast<const int*>((const unsigned char*)pack + g.bytes) + F_COUNT;
     a.masks = masks; a.raw_den = raw_den; a.d_rgb = d_raw_rgb; a.d_den = d_raw_den; a.sdot = sdot;
     a.mean = mean; a.cov = cov;
     a.drgb_t = drgb_t; a.dhv_t = dhv_t; a.d8_t = d8_t; a.delta_t = delta_t; a.coef_t = coef_t; a.d_mean = d_mean;
+    a.amax = planes == 2 ? amax : nullptr;
     LAUNCH_CHAIN(k_chain_bwd, planes, a.nst, a, (hipStream_t)stream, 5, (double)M * (flops_mlp(nc) - (d_mean ? 0.0 : 2.0 * 2 * 96 * 256)));
 }
 
@@ -1582,7 +2107,7 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
                    void* stream) {
     if (n < 1 || n > 3) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (planes != 1 && planes != 3) return PN_ERR_UNSUPPORTED;
+    if (planes != 1 && planes != 2 && planes != 3) return PN_ERR_UNSUPPORTED;
     if (!ev || !grads || !work) return PN_ERR_NULL;
     hipStream_t s = (hipStream_t)stream;
     const PnLayout L = pn_layout(nc);
@@ -1594,9 +2119,16 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
             if (!ev[e].edot_t || !ev[e].tang_t || !ev[e].coef_t) return PN_ERR_NULL;
             ++n2;
         }
+        if (planes == 2 && !ev[e].amax) return PN_ERR_NULL;
     }
     if (n + n2 > 4) return PN_ERR_UNSUPPORTED;
-    auto run = [&](const WgJob& j) { return planes == 3 ? run_wgrad_job<3>(j, work, work_floats, s) : run_wgrad_job<1>(j, work, work_floats, s); };
+    // planes = 2: a weight gradient sums over ALL samples, so each operand tensor gets ONE power of two, from the maxima
+    // the chain kernels left in the evaluation's table
+    auto run = [&](const WgJob& j) {
+        return planes == 3 ? run_wgrad_job<3>(j, work, work_floats, s)
+                           : (planes == 2 ? run_wgrad_job<2>(j, work, work_floats, s) : run_wgrad_job<1>(j, work, work_floats, s));
+    };
+    auto am = [&](int e, int slot) -> const uint32_t* { return ev[e].amax ? ev[e].amax + slot : nullptr; };
     auto mp = [&](int e) { return pn_pad(ev[e].M); };
     auto act = [&](int e, int slot) { return ev[e].acts_t + act_off(slot, mp(e)); };
     int rc;
@@ -1606,11 +2138,11 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
         for (int e = 0; e < n; ++e) {
             const int64_t Mp = mp(e);
             j.seg[j.nseg++] = WSeg{ev[e].delta_t + (int64_t)l * Mp * 256, l == 0 ? ev[e].enc_t : act(e, l - 1), Mp / 16, 256,
-                                   l == 0 ? 96 : 256, 1};
+                                   l == 0 ? 96 : 256, 1, am(e, AM_DELTA0 + l), am(e, l == 0 ? AM_ENC : AM_ACT0 + l - 1)};
             if (ev[e].rs_t)
                 j.seg[j.nseg++] = WSeg{ev[e].rs_t + (int64_t)l * Mp * 256,
                                        l == 0 ? ev[e].edot_t : ev[e].tang_t + (int64_t)(l - 1) * Mp * 256, Mp / 16, 256,
-                                       l == 0 ? 96 : 256, 0};
+                                       l == 0 ? 96 : 256, 0, am(e, AM_RS0 + l), am(e, l == 0 ? AM_EDOT : AM_TANG0 + l - 1)};
         }
         j.cfg = l == 0 ? 1 : 0;
         j.rows = 256;
@@ -1623,8 +2155,11 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
             WgJob k{};
             for (int e = 0; e < n; ++e) {
                 const int64_t Mp = mp(e);
-                k.seg[k.nseg++] = WSeg{ev[e].delta_t + (int64_t)5 * Mp * 256, ev[e].enc_t, Mp / 16, 256, 96, 0};
-                if (ev[e].rs_t) k.seg[k.nseg++] = WSeg{ev[e].rs_t + (int64_t)5 * Mp * 256, ev[e].edot_t, Mp / 16, 256, 96, 0};
+                k.seg[k.nseg++] = WSeg{ev[e].delta_t + (int64_t)5 * Mp * 256, ev[e].enc_t, Mp / 16, 256, 96, 0,
+                                       am(e, AM_DELTA0 + 5), am(e, AM_ENC)};
+                if (ev[e].rs_t)
+                    k.seg[k.nseg++] = WSeg{ev[e].rs_t + (int64_t)5 * Mp * 256, ev[e].edot_t, Mp / 16, 256, 96, 0,
+                                           am(e, AM_RS0 + 5), am(e, AM_EDOT)};
             }
             k.cfg = 1; k.rows = 256; k.cols = 96;
             k.dst = grads + L.w[5] + 256; k.ldd = 352; k.dbias = nullptr;
@@ -1633,18 +2168,20 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     }
     {  // extra layer: d bottleneck^T h7
         WgJob j{};
-        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t, act(e, 7), mp(e) / 16, 288, 256, 1};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t, act(e, 7), mp(e) / 16, 288, 256, 1, am(e, AM_D8B), am(e, AM_ACT0 + 7)};
         j.cfg = 0; j.rows = 256; j.cols = 256; j.dst = grads + L.we; j.ldd = 256; j.dbias = grads + L.be;
         if ((rc = run(j)) != PN_OK) return rc;
     }
     {  // density head: d raw_density^T h7 (+ softplus' rows against hdot_7 into row 0)
         WgJob j{};
-        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t + 256 * TILE, act(e, 7), mp(e) / 16, 288, 256, 1};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t + 256 * TILE, act(e, 7), mp(e) / 16, 288, 256, 1, am(e, AM_D8D), am(e, AM_ACT0 + 7)};
         j.cfg = 3; j.rows = nc; j.cols = 256; j.dst = grads + L.wd; j.ldd = 256; j.dbias = grads + L.bd;
         if ((rc = run(j)) != PN_OK) return rc;
         WgJob k{};
         for (int e = 0; e < n; ++e)
-            if (ev[e].rs_t) k.seg[k.nseg++] = WSeg{ev[e].coef_t, ev[e].tang_t + (int64_t)7 * mp(e) * 256, mp(e) / 16, 32, 256, 0};
+            if (ev[e].rs_t)
+                k.seg[k.nseg++] = WSeg{ev[e].coef_t, ev[e].tang_t + (int64_t)7 * mp(e) * 256, mp(e) / 16, 32, 256, 0,
+                                       am(e, AM_COEF), am(e, AM_TANG0 + 7)};
         if (k.nseg) {
             k.cfg = 3; k.rows = 1; k.cols = 256; k.dst = grads + L.wd; k.ldd = 256; k.dbias = nullptr;
             if ((rc = run(k)) != PN_OK) return rc;
@@ -1652,14 +2189,14 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     }
     {  // view layer: d hv^T [bottleneck | view encoding]
         WgJob j{};
-        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].dhv_t, act(e, 8), mp(e) / 16, 128, 288, 1};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].dhv_t, act(e, 8), mp(e) / 16, 128, 288, 1, am(e, AM_DHV), am(e, AM_ACT0 + 8)};
         j.cfg = 2; j.rows = 128; j.cols = PN_WIDTH + PN_VIEW_DIM; j.dst = grads + L.wv; j.ldd = PN_WIDTH + PN_VIEW_DIM;
         j.dbias = grads + L.bv;
         if ((rc = run(j)) != PN_OK) return rc;
     }
     {  // colour head: d rgb^T hv
         WgJob j{};
-        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].drgb_t, act(e, 9), mp(e) / 16, 32, 128, 1};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].drgb_t, act(e, 9), mp(e) / 16, 32, 128, 1, am(e, AM_DRGB), am(e, AM_ACT0 + 9)};
         j.cfg = 4; j.rows = 3; j.cols = 128; j.dst = grads + L.wc; j.ldd = 128; j.dbias = grads + L.bc;
         if ((rc = run(j)) != PN_OK) return rc;
     }

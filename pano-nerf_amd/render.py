@@ -25,7 +25,7 @@ def _f32(x):
 
 class _Eval:
     """Buffers of one MLP evaluation over M sample rows (all caller-owned HBM).  planes = 0: layer-wise GEMM path
-    (row-major activations); planes = 3 / 1: fused chain kernels (T32 sample-minor tensors, see pn_chain.hip)."""
+    (row-major activations); planes = 3 / 2 / 1: fused chain kernels (T32 sample-minor tensors, see pn_chain.hip)."""
 
     def __init__(self, M, rows_per_ray, viewdirs, nc, dev, planes=0, keep=True):
         self.M, self.rows_per_ray, self.nc = M, rows_per_ray, nc
@@ -40,10 +40,14 @@ class _Eval:
             self.enc = e(Mp * 96)                                          # T [96]
             # T h0..h7, bottleneck | viewenc, view hidden — only the backward re-reads them: not kept in inference
             self.acts = e(int(_lib.load().pn_chain_acts_floats(M))) if keep else None
+            # planes = 2, training: largest |x| of every T tensor (one power-of-two scale per tensor in the weight gradients)
+            self.amax = (torch.empty(int(_lib.load().pn_chain_amax_slots()), dtype=torch.int32, device=dev)
+                         if (planes == 2 and keep) else None)
         else:
             self.enc = e(Mp, 96)
             self.viewenc, self.viewbias = e(self.view_rows, 27), e(self.view_rows, 128)
             self.acts = e(10, Mp, 256)
+            self.amax = None
         self.masks = torch.empty(9, Mp, 8, dtype=torch.int32, device=dev)  # ReLU gates as bit masks
         self.raw_rgb, self.raw_den = e(M, 3), e(M, nc)
         self.t = None
@@ -53,9 +57,9 @@ class _Eval:
 
 def _planes_of(mode):
     try:
-        return {"fused": 3, "fused_bf16": 1, "layerwise": 0}[mode]
+        return {"fused": 3, "fused_f16x2": 2, "fused_bf16": 1, "layerwise": 0}[mode]
     except KeyError:
-        raise ValueError(f"mlp_mode must be 'fused', 'fused_bf16' or 'layerwise', got {mode!r}")
+        raise ValueError(f"mlp_mode must be 'fused', 'fused_f16x2', 'fused_bf16' or 'layerwise', got {mode!r}")
 
 
 class _Cfg:
@@ -69,7 +73,7 @@ def _mlp_forward(ev, params, wpack, st):
     if ev.planes:
         _lib.call("pn_chain_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, ev.planes, wpack.data_ptr(),
                   ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), _lib.ptr(ev.acts),
-                  ev.masks.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), st)
+                  ev.masks.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), _lib.ptr(ev.amax), st)
         return
     _lib.call("pn_mlp_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, params.data_ptr(), wpack.data_ptr(),
               ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
@@ -138,7 +142,7 @@ class _ChainEvalC(ctypes.Structure):
     _fields_ = [("M", ctypes.c_int64), ("enc_t", ctypes.c_void_p), ("acts_t", ctypes.c_void_p),
                 ("drgb_t", ctypes.c_void_p), ("dhv_t", ctypes.c_void_p), ("d8_t", ctypes.c_void_p),
                 ("delta_t", ctypes.c_void_p), ("rs_t", ctypes.c_void_p), ("edot_t", ctypes.c_void_p),
-                ("tang_t", ctypes.c_void_p), ("coef_t", ctypes.c_void_p)]
+                ("tang_t", ctypes.c_void_p), ("coef_t", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
 
 
 def _chain_backward(ev, cfg, params, pack, d_raw_rgb, d_raw_den, v, d_mean, st):
@@ -154,13 +158,13 @@ def _chain_backward(ev, cfg, params, pack, d_raw_rgb, d_raw_den, v, d_mean, st):
         ev.edot, ev.tang, sdot = e(Mp * 96), e(8 * Mp * 256), e(ev.M)
         _lib.call("pn_chain_tangent", ev.M, ev.nc, ev.planes, params.data_ptr(), pack.data_ptr(), ev.mean.data_ptr(),
                   ev.cov.data_ptr(), ev.masks.data_ptr(), v.data_ptr(), ev.edot.data_ptr(), ev.tang.data_ptr(),
-                  sdot.data_ptr(), st)
+                  sdot.data_ptr(), _lib.ptr(ev.amax), st)
         ev.coef = z(Mp * 32)
     ev.drgb, ev.dhv, ev.d8, ev.delta = z(Mp * 32), e(Mp * 128), z(Mp * 288), e(8 * Mp * 256)
     _lib.call("pn_chain_backward", ev.M, ev.nc, ev.planes, cfg.density_bias, pack.data_ptr(), ev.masks.data_ptr(),
               ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(), _lib.ptr(sdot), ev.mean.data_ptr(),
               ev.cov.data_ptr(), ev.drgb.data_ptr(), ev.dhv.data_ptr(), ev.d8.data_ptr(), ev.delta.data_ptr(),
-              _lib.ptr(ev.coef), _lib.ptr(d_mean), st)
+              _lib.ptr(ev.coef), _lib.ptr(d_mean), _lib.ptr(ev.amax), st)
 
 
 def _chain_wgrad(evals, nc, planes, flat_grad, st):
@@ -172,7 +176,7 @@ def _chain_wgrad(evals, nc, planes, flat_grad, st):
         arr[i] = _ChainEvalC(ev.M, ev.enc.data_ptr(), ev.acts.data_ptr(), ev.drgb.data_ptr(), ev.dhv.data_ptr(),
                              ev.d8.data_ptr(), ev.delta.data_ptr(), ev.rsweep.data_ptr() if second else None,
                              ev.edot.data_ptr() if second else None, ev.tang.data_ptr() if second else None,
-                             ev.coef.data_ptr() if second else None)
+                             ev.coef.data_ptr() if second else None, _lib.ptr(ev.amax))
     n = int(lib.pn_chain_wgrad_work_floats())
     work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
     _lib.check(lib.pn_chain_wgrad(len(evals), ctypes.cast(arr, ctypes.c_void_p), nc, planes, flat_grad.data_ptr(),
@@ -226,7 +230,8 @@ class _RenderFn(torch.autograd.Function):
                 if planes:
                     _lib.call("pn_chain_density_grad", M, nc, planes, cfg.density_bias, params.data_ptr(),
                               wpack.data_ptr(), e1.mean.data_ptr(), e1.cov.data_ptr(), e1.masks.data_ptr(),
-                              e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), int(keep), e1.gmean.data_ptr(), st)
+                              e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), int(keep), e1.gmean.data_ptr(),
+                              _lib.ptr(e1.amax), st)
                 else:
                     scratch = e(e1.Mp, 96)
                     _lib.call("pn_density_grad", M, nc, cfg.density_bias, params.data_ptr(), wpack.data_ptr(),
@@ -425,11 +430,13 @@ class _RenderBase(torch.nn.Module):
         # time-shared run measured 2 % SLOWER (62.4 k vs 61.0 k rays/s at 4096 rays, 50.8 k vs 49.4 k at 512)
         self.overlap_weight_grads = False
         self.batch_weight_grads = True    # one weight-gradient GEMM per layer over env + level-1 + level-0 rows
-        # MLP arithmetic / kernel family: "fused" = on-chip chains, exact 3-term bf16 split (fp32 accuracy);
-        # "fused_bf16" = on-chip chains, plain bf16 operands (BASELINE configs[1]); "layerwise" = one exact-fp32 MFMA
-        # GEMM per layer (round-1 path).  PN_MLP_MODE overrides the default.
+        # MLP arithmetic / kernel family.  "fused_f16x2" (default) = on-chip chains, every fp32 operand as an fp16 pair
+        # x 2^e = h + l (|error| < 2^-24 |x|; one power-of-two scale per weight matrix and per sample / tensor), three
+        # partial products, fp32 accumulate; "fused" = the same kernels with the exact 3-term bf16 split (six partial
+        # products); "fused_bf16" = plain bf16 operands (BASELINE configs[1]); "layerwise" = one exact-fp32 MFMA GEMM
+        # per layer (round-1 path).  PN_MLP_MODE overrides the default.
         import os
-        self.mlp_mode = os.environ.get("PN_MLP_MODE", "fused")
+        self.mlp_mode = os.environ.get("PN_MLP_MODE", "fused_f16x2")
 
     def _noise(self, randomized, B, dev, want_env):
         if not randomized:

@@ -42,9 +42,10 @@ for step in range(2):
     assert model.mlp.is_flat() and bool(torch.isfinite(model.mlp.flat).all())
     # the packed weights the kernels read must follow the in-place optimizer step
     st = torch.cuda.current_stream().cuda_stream
-    used = model.mlp.chain_packed(st, 3).clone()
+    planes = pn.render._planes_of(model.mlp_mode)
+    used = model.mlp.chain_packed(st, planes).clone()
     fresh = torch.empty_like(used)
-    pn._lib.call("pn_chain_pack", model.mlp.flat.data_ptr(), 5, 3, fresh.data_ptr(), st)
+    pn._lib.call("pn_chain_pack", model.mlp.flat.data_ptr(), 5, planes, fresh.data_ptr(), st)
     torch.cuda.synchronize()
     assert torch.equal(used, fresh), "stale packed weights after optimizer.step()"
 # replicas stay identical: same averaged gradient, same update

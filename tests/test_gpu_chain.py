@@ -35,7 +35,7 @@ class Ev:
 
 class EvalC(ctypes.Structure):
     _fields_ = [("M", ctypes.c_int64)] + [(k, ctypes.c_void_p) for k in
-                ("enc_t", "acts_t", "drgb_t", "dhv_t", "d8_t", "delta_t", "rs_t", "edot_t", "tang_t", "coef_t")]
+                ("enc_t", "acts_t", "drgb_t", "dhv_t", "d8_t", "delta_t", "rs_t", "edot_t", "tang_t", "coef_t", "amax")]
 
 
 def rel(a, b):
@@ -43,8 +43,9 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+@pytest.mark.parametrize("planes", [3, 2])  # exact bf16 three-term split / fp16 pair with per-sample scaling
 @pytest.mark.parametrize("M,rows_per_ray,view_rows,nc", [(2048, 32, 64, 5), (3000, 10, 10, 5), (130 * 7, 7, 130, 1)])
-def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc):
+def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc, planes):
     from pano_nerf_amd import _lib
     lib = _lib.load()
     E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev())
@@ -68,7 +69,6 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc):
     d_rgb, d_den, v = torch.randn(M, 3, generator=gen), torch.randn(M, nc, generator=gen), torch.randn(M, 3, generator=gen)
     Mp = int(lib.pn_pad_rows(M))
     dbias = -1.0
-    planes = 3
     pack = torch.empty(int(lib.pn_chain_pack_bytes(planes)), dtype=torch.uint8, device=dev())
     _lib.call("pn_chain_pack", flat_d.data_ptr(), nc, planes, pack.data_ptr(), st())
     ev = Ev()
@@ -77,8 +77,10 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc):
     enc_t, acts_t = E(Mp * 96), E(int(lib.pn_chain_acts_floats(M)))
     ev.masks = torch.zeros(9, Mp, 8, dtype=torch.int32, device=dev())
     rr, rd = E(M, 3), E(M, nc)
+    amax = torch.empty(int(lib.pn_chain_amax_slots()), dtype=torch.int32, device=dev())  # maxima of the T tensors (planes = 2)
     _lib.call("pn_chain_forward", M, rows_per_ray, view_rows, nc, planes, pack.data_ptr(), mean_d.data_ptr(), cov_d.data_ptr(),
-              vd_d.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), ev.masks.data_ptr(), rr.data_ptr(), rd.data_ptr(), st())
+              vd_d.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), ev.masks.data_ptr(), rr.data_ptr(), rd.data_ptr(),
+              amax.data_ptr(), st())
     torch.cuda.synchronize()
 
     # ---- fp64 model (natural gates): forward values
@@ -115,22 +117,24 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc):
     # ---- kernels
     rs_t, gmean = E(8, Mp * 256), E(M, 3)
     _lib.call("pn_chain_density_grad", M, nc, planes, dbias, flat_d.data_ptr(), pack.data_ptr(), mean_d.data_ptr(),
-              cov_d.data_ptr(), ev.masks.data_ptr(), rd.data_ptr(), rs_t.data_ptr(), 1, gmean.data_ptr(), st())
-    assert rel(gmean.cpu(), gmean64.detach()) < 5e-5
+              cov_d.data_ptr(), ev.masks.data_ptr(), rd.data_ptr(), rs_t.data_ptr(), 1, gmean.data_ptr(), amax.data_ptr(), st())
+    # 5e-5 holds for the exact three-term split; the fp16 pair (operands to 2^-24, per-sample scale) is gated at the contract
+    tol = 5e-5 if planes == 3 else 1e-4
+    assert rel(gmean.cpu(), gmean64.detach()) < tol
     v_d, drgb_d, dden_d = v.to(dev()), d_rgb.to(dev()), d_den.to(dev())
     edot_t, tang_t, sdot = E(Mp * 96), E(8, Mp * 256), E(M)
     _lib.call("pn_chain_tangent", M, nc, planes, flat_d.data_ptr(), pack.data_ptr(), mean_d.data_ptr(), cov_d.data_ptr(),
-              ev.masks.data_ptr(), v_d.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), sdot.data_ptr(), st())
+              ev.masks.data_ptr(), v_d.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), sdot.data_ptr(), amax.data_ptr(), st())
     drgb_t, dhv_t, d8_t, delta_t, coef_t = Z(Mp * 32), E(Mp * 128), Z(Mp * 288), E(8, Mp * 256), Z(Mp * 32)
     d_mean = E(M, 3)
     _lib.call("pn_chain_backward", M, nc, planes, dbias, pack.data_ptr(), ev.masks.data_ptr(), rd.data_ptr(), drgb_d.data_ptr(),
               dden_d.data_ptr(), sdot.data_ptr(), mean_d.data_ptr(), cov_d.data_ptr(), drgb_t.data_ptr(), dhv_t.data_ptr(),
-              d8_t.data_ptr(), delta_t.data_ptr(), coef_t.data_ptr(), d_mean.data_ptr(), st())
+              d8_t.data_ptr(), delta_t.data_ptr(), coef_t.data_ptr(), d_mean.data_ptr(), amax.data_ptr(), st())
     grads = Z(total)
     wfl = int(lib.pn_chain_wgrad_work_floats())
     work = E(wfl)
     evc = EvalC(M, enc_t.data_ptr(), acts_t.data_ptr(), drgb_t.data_ptr(), dhv_t.data_ptr(), d8_t.data_ptr(), delta_t.data_ptr(),
-                rs_t.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), coef_t.data_ptr())
+                rs_t.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), coef_t.data_ptr(), amax.data_ptr())
     lib.pn_chain_wgrad.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_int64, ctypes.c_void_p]
     _lib.check(lib.pn_chain_wgrad(1, ctypes.byref(evc), nc, planes, grads.data_ptr(), work.data_ptr(), wfl, st()), "pn_chain_wgrad")
@@ -145,7 +149,7 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc):
         (dz,) = torch.autograd.grad(sd, den_g, retain_graph=True)
         L1 = (rgb_g.view(M, 3) * d_rgb.double()).sum() + (den_g.view(M, nc) * (d_den.double() + dz.view(M, nc).detach())).sum()
         (dmean_first,) = torch.autograd.grad(L1, mean64)
-    assert rel(d_mean.cpu(), dmean_first) < 5e-5
+    assert rel(d_mean.cpu(), dmean_first) < tol
     got = grads.cpu().numpy().astype(np.float64)
     worst = 0.0
     for k in ORDER:

@@ -90,7 +90,7 @@ def check_grads(model, g, prefix):
         assert float(np.median(err)) < 1e-4 * max(float(np.max(np.abs(ref))), 1e-12), (k, float(np.median(err)))
 
 
-MODES = ["fused", "layerwise"]  # on-chip chains with the exact 3-term bf16 split (default) / one fp32-MFMA GEMM per layer
+MODES = ["fused", "fused_f16x2", "layerwise"]  # on-chip chains with the exact 3-term bf16 split (default) / one fp32-MFMA GEMM per layer
 
 
 @pytest.mark.parametrize("mode", MODES)

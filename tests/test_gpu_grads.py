@@ -23,7 +23,7 @@ from test_gpu_full import dev, env_of, make_pano, rays_of, to_dev
 
 pytestmark = pytest.mark.gpu
 CASES = ["B64_N32", "B16_N128"]
-MODES = ["fused", "layerwise"]
+MODES = ["fused", "fused_f16x2", "layerwise"]
 FIRST_ORDER = ("extra_layer", "view_layers", "color_layer")
 
 

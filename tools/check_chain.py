@@ -1,10 +1,13 @@
 """GPU check of the fused forward chain (pn_chain_forward) against the layer-wise exact-fp32 path (pn_mlp_forward)."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pano_nerf_amd import _lib
 
 dev = torch.device("cuda:0")
+import os as _os
+if _os.environ.get("PN_LIB"):  # a variant build of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = _os.path.abspath(_os.environ["PN_LIB"])
 lib = _lib.load()
 st = lambda: torch.cuda.current_stream().cuda_stream
 E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -43,9 +46,11 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     acts_t = E(int(lib.pn_chain_acts_floats(M)))
     masks_f = torch.zeros(9, Mp, 8, dtype=torch.int32, device=dev)
     rr2, rd2 = E(M, 3), E(M, nc)
-    call = lambda: _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
-                             vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(),
-                             rd2.data_ptr(), st())
+    import os
+    keep = os.environ.get("PN_CHECK_NO_ACTS") is None  # PN_CHECK_NO_ACTS=1: time the inference variant (activations not kept)
+    call = lambda k=True: _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(),
+                                    cov.data_ptr(), vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr() if (k or keep) else None,
+                                    masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(), None, st())
     call()
     torch.cuda.synchronize()
 
@@ -79,11 +84,11 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            call()
+            call(False)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
-        flops = M * 2 * 611328.0 * (6 if planes == 3 else 1)
-        print(f"  fused forward {dt*1e3:.3f} ms  ({M*2*611328.0/dt/1e12:.1f} TF fp32-equivalent, {flops/dt/1e12:.0f} TF bf16 issued)")
+        flops = M * 2 * 611328.0 * {3: 6, 2: 3, 1: 1}[planes]
+        print(f"  fused forward {dt*1e3:.3f} ms  ({M*2*611328.0/dt/1e12:.1f} TF fp32-equivalent, {flops/dt/1e12:.0f} TF issued on the matrix cores)")
         ref = lambda: _lib.call("pn_mlp_forward", M, rows_per_ray, R, nc, params.data_ptr(), wpack.data_ptr(), mean.data_ptr(),
                                 cov.data_ptr(), vd.data_ptr(), enc.data_ptr(), venc.data_ptr(), vb.data_ptr(), acts.data_ptr(),
                                 masks.data_ptr(), rr.data_ptr(), rd.data_ptr(), st())
@@ -97,8 +102,9 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
 
 
 if __name__ == "__main__":
-    run(64 * 32, 32, 3)
-    run(16 * 128 + 0, 128, 1)
-    run(1000 * 10, 10, 3)
-    run(4096 * 128, 128, 3, reps=5)
-    run(4096 * 128, 128, 1, reps=5)
+    modes = [int(x) for x in sys.argv[1:]] or [3, 2, 1]  # planes: 3 bf16 three-term, 2 fp16 pair, 1 plain bf16
+    for pl in modes:
+        run(64 * 32, 32, pl)
+        run(1000 * 10, 10, pl)
+    for pl in modes:
+        run(4096 * 128, 128, pl, reps=5)

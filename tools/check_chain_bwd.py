@@ -1,10 +1,13 @@
 """GPU check of the fused reverse sweep / tangent sweep / backward chain against the layer-wise exact-fp32 path."""
 import ctypes, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pano_nerf_amd import _lib
 
 dev = torch.device("cuda:0")
+import os as _os
+if _os.environ.get("PN_LIB"):  # a variant build of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = _os.path.abspath(_os.environ["PN_LIB"])
 lib = _lib.load()
 st = lambda: torch.cuda.current_stream().cuda_stream
 E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -64,22 +67,24 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     enc_t, acts_t = E(Mp * 96), E(int(lib.pn_chain_acts_floats(M)))
     masks_f = torch.zeros(9, Mp, 8, dtype=torch.int32, device=dev)
     rr2, rd2 = E(M, 3), E(M, nc)
+    amax = torch.empty(int(lib.pn_chain_amax_slots()), dtype=torch.int32, device=dev)
     _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
-              vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(), st())
+              vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(),
+              amax.data_ptr(), st())
     rs_t, gmean2 = E(8, Mp * 256), E(M, 3)
     f_dgrad = lambda: _lib.call("pn_chain_density_grad", M, nc, planes, dbias, params.data_ptr(), pack.data_ptr(), mean.data_ptr(),
-                                cov.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(), rs_t.data_ptr(), 1, gmean2.data_ptr(), st())
+                                cov.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(), rs_t.data_ptr(), 1, gmean2.data_ptr(), amax.data_ptr(), st())
     f_dgrad()
     edot_t, tang_t, sdot = E(Mp * 96), E(8, Mp * 256), E(M)
     f_tan = lambda: _lib.call("pn_chain_tangent", M, nc, planes, params.data_ptr(), pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
-                              masks_f.data_ptr(), v.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), sdot.data_ptr(), st())
+                              masks_f.data_ptr(), v.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), sdot.data_ptr(), amax.data_ptr(), st())
     f_tan()
     drgb_t, dhv_t, d8_t, delta_t, coef_t = Z(Mp * 32), E(Mp * 128), Z(Mp * 288), E(8, Mp * 256), Z(Mp * 32)
     d_mean2 = E(M, 3)
     f_bwd = lambda: _lib.call("pn_chain_backward", M, nc, planes, dbias, pack.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(),
                               d_rgb.data_ptr(), d_den.data_ptr(), sdot.data_ptr(), mean.data_ptr(), cov.data_ptr(),
                               drgb_t.data_ptr(), dhv_t.data_ptr(), d8_t.data_ptr(), delta_t.data_ptr(), coef_t.data_ptr(),
-                              d_mean2.data_ptr(), st())
+                              d_mean2.data_ptr(), amax.data_ptr(), st())
     f_bwd()
     torch.cuda.synchronize()
     print(f"M={M} planes={planes}")
@@ -111,9 +116,9 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
 
     class Ev(ctypes.Structure):
         _fields_ = [("M", ctypes.c_int64)] + [(k, ctypes.c_void_p) for k in
-                    ("enc_t", "acts_t", "drgb_t", "dhv_t", "d8_t", "delta_t", "rs_t", "edot_t", "tang_t", "coef_t")]
+                    ("enc_t", "acts_t", "drgb_t", "dhv_t", "d8_t", "delta_t", "rs_t", "edot_t", "tang_t", "coef_t", "amax")]
     ev = Ev(M, enc_t.data_ptr(), acts_t.data_ptr(), drgb_t.data_ptr(), dhv_t.data_ptr(), d8_t.data_ptr(), delta_t.data_ptr(),
-            rs_t.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), coef_t.data_ptr())
+            rs_t.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), coef_t.data_ptr(), amax.data_ptr())
     grads_f = Z(total)
     wfl = int(lib.pn_chain_wgrad_work_floats())
     wk = E(wfl)
@@ -151,6 +156,9 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
 
 
 if __name__ == "__main__":
-    run(64 * 32, 32, 3)
-    run(1000 * 10, 10, 1)
-    run(4096 * 128, 128, 3, reps=5)
+    modes = [int(x) for x in sys.argv[1:]] or [3, 2, 1]
+    for pl in modes:
+        run(64 * 32, 32, pl)
+        run(1000 * 10, 10, pl)
+    for pl in modes:
+        run(4096 * 128, 128, pl, reps=5)

@@ -2,7 +2,7 @@
 Shader-clock stamps of wave 0 of workgroup 0 on its second tile."""
 import ctypes, sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pano_nerf_amd import _lib
 import tools.check_chain as cc
 
@@ -23,3 +23,12 @@ for i in range(1, 25):
     print(f"{names[i]:20s} {t[i]-prev:8d} cycles")
     prev = t[i]
 print("tile total", t[24] - t[0])
+print("inside ipe (any tile of wave 0): loads landed -> math done", t[31] - t[30], " -> stores issued", t[32] - t[31])
+for i in range(16):
+    v = t[40 + i]
+    if v:
+        hw = v & 0xfffffff
+        print(f"block {(i & 7) + (256 if i >= 8 else 0):4d}: lds_alloc {v >> 32:#010x} xcc {(v >> 28) & 0xf} hw_id {hw:#09x} wave {hw & 0xf} simd {(hw >> 4) & 3} cu {(hw >> 8) & 0xf} sh {(hw >> 12) & 1} se {(hw >> 13) & 7}")
+n = max(t[59], 1)
+print(f"ring acquires of wave 0 / workgroup 0 over the kernel: {t[59]}; mean cycles waiting for own LDS reads {t[56]/n:.0f}, "
+      f"for the chunk's DMA {t[57]/n:.0f}, at the barrier {t[58]/n:.0f} (each stamp costs a scalar-memory round trip)")
