@@ -43,7 +43,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #define PN_CHAIN_TILE 16
 #endif
 #ifndef PN_ABL_CHAIN  // timing ablations of the GEMM step (wrong results; never in the shipped build): bit 0 no refill DMA,
-#define PN_ABL_CHAIN 0  // bit 1 no fragment reads, bit 2 no MFMAs, bit 3 no ring barrier
+#define PN_ABL_CHAIN 0  // bit 1 no fragment reads, bit 2 no MFMAs, bit 3 no ring barrier, bit 4 no T-layout stores
 #endif
 #define HALF_PI_F 1.5707963705062866f
 constexpr int TILE = PN_CHAIN_TILE;  // features per accumulator tile = samples per wave
@@ -690,8 +690,13 @@ __device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB]
     return e;
 }
 // T-layout store: base points at [block][0][0] + (lane % TILE) + 4 * (lane / TILE) * TILE floats
+// (Measured: these one-dword-per-feature stores cost 15-21 % of a chain kernel's time, PN_ABL_CHAIN bit 4 - and a
+// [feature / 4][sample][4] layout with one 16-byte store per quad block, 1 KB contiguous per wave instruction, gained only
+// 0-4 % while the weight-gradient GEMM, which then needs transposing fragment reads, lost 19 %: the cost is the written
+// bytes, not the instruction count.)
 template <int NT>
 __device__ __forceinline__ void store_t(float* base, const accv (&acc)[NT]) {
+    if constexpr (PN_ABL_CHAIN & 16) return;  // (timing ablation: no T stores)
 #pragma unroll
     for (int qb = 0; qb < NT * ACCQ; ++qb)
 #pragma unroll

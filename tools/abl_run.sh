@@ -1,7 +1,7 @@
 #!/bin/bash
 # times the forward chain of every ablation variant found (tools/build_variant.sh), same box, back to back
 cd "$(dirname "$0")/.."
-for v in "" _abl1 _abl2 _abl3 _abl4 _abl7 _abl11; do
+for v in "" _abl1 _abl2 _abl3 _abl4 _abl7 _abl11 _abl16 _abl20; do
   f=pano-nerf_amd/libpanonerf_hip$v.so
   [ -f $f ] || continue
   echo "== $f"
