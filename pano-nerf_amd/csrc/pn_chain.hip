@@ -161,12 +161,14 @@ struct PackTable {
 };
 
 // NP = 2 only: one power-of-two scale per packed GEMM, 2^wexp, that takes the largest |weight| of its segments into
-// [2^14, 2^15) (fp16 holds 65504), clamped to 2^+-40.  One workgroup per GEMM of the table.
+// [2^14, 2^15) (fp16 holds 65504).  The exponent is capped at +40 (a tensor of zeros or of values below 2^-25: scaled sums
+// and the bias that joins them stay far inside fp32's range); large values are never capped - they scale down.  One
+// workgroup per GEMM of the table.
 constexpr int EXP_TOP = 15;   // frexp exponent of the scaled maximum
-constexpr int EXP_CLAMP = 40;
+constexpr int EXP_CAP = 40;
 __device__ __forceinline__ int scale_exp(float amax) {
     const int e = EXP_TOP - __builtin_amdgcn_frexp_expf(amax);
-    return e < -EXP_CLAMP ? -EXP_CLAMP : (e > EXP_CLAMP ? EXP_CLAMP : e);
+    return e > EXP_CAP ? EXP_CAP : e;
 }
 __global__ void k_chain_wexp(PackTable tab, const float* params, int* wexp) {
     const PackLayer& L = tab.L[blockIdx.x];
