@@ -1,0 +1,22 @@
+#!/bin/bash
+# The round's measurement pass on one GPU box: default bench, rocprofv3 kernel table, the two PMC traffic passes, and the
+# other modes / the 512-ray share.  Writes under gpurun_out/final/.
+set -e
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 420 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+echo "default bench done"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-inference > $O/bench_under_rocprof.json 2> $O/kt.err
+echo "kernel trace done"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-inference > $O/pmc_f.json 2> $O/pmc_f.err
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-inference > $O/pmc_w.json 2> $O/pmc_w.err
+echo "pmc done"
+cd $R
+timeout -k 10 200 python3 bench.py --global-batch 512 --steps 20 --warmup 5 --no-cpu-baseline --no-inference > $O/bench_b512.json 2> $O/bench_b512.err
+for m in fused fused_bf16 layerwise; do
+  timeout -k 10 200 python3 bench.py --mlp-mode $m --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$m.json 2> $O/bench_$m.err
+done
+echo "modes done"
