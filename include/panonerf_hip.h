@@ -208,8 +208,9 @@ int pn_chain_tangent(int64_t M, int num_density_channels, int planes, const floa
                      const float* mean, const float* cov, const uint32_t* masks, const float* v_gradmean,
                      float* edot_t /*T [Mp*96]*/, float* tang_t /*T [8][Mp*256]*/, float* sdot /*[M]*/, uint32_t* amax,
                      void* stream);
-/* data-gradient chain.  drgb_t T [Mp*32], d8_t T [Mp*288], coef_t T [Mp*32] must be zero-filled by the caller
- * once (the kernel rewrites the rows it owns); sdot / coef_t: second-order path (both or neither); d_mean nullable. */
+/* data-gradient chain.  drgb_t T [Mp*32], d8_t T [Mp*288], coef_t T [Mp*32]: with pn_chain_tile() = 32 the caller
+ * zero-fills them once (the kernel writes 16 of their 32 padded features); with the default 16 the kernel writes them
+ * whole.  sdot / coef_t: second-order path (both or neither); d_mean nullable. */
 int pn_chain_backward(int64_t M, int num_density_channels, int planes, float density_bias, const void* pack,
                       const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
                       const float* d_raw_density, const float* sdot, const float* mean, const float* cov,

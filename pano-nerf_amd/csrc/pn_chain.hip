@@ -170,13 +170,14 @@ __device__ __forceinline__ int scale_exp(float amax) {
     const int e = EXP_TOP - __builtin_amdgcn_frexp_expf(amax);
     return e > EXP_CAP ? EXP_CAP : e;
 }
-__global__ void k_chain_wexp(PackTable tab, const float* params, int* wexp) {
+constexpr int WEXP_SLICES = 16;  // workgroups per GEMM of the table (one alone took 67 us on the transposed 256 x 352 matrix)
+__global__ void k_chain_wexp(PackTable tab, const float* params, uint32_t* wmax) {
     const PackLayer& L = tab.L[blockIdx.x];
     float m = 0.f;
     for (int s = 0; s < L.nseg; ++s) {
         const PackSeg& sg = L.seg[s];
         const int n = L.rows_valid * sg.kvalid;
-        for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        for (int idx = threadIdx.x + blockDim.x * blockIdx.y; idx < n; idx += blockDim.x * WEXP_SLICES) {
             const int i = idx / sg.kvalid, kr = idx - i * sg.kvalid;
             const float x = sg.transposed ? params[sg.off + (int64_t)kr * sg.ld + sg.col0 + i]
                                           : params[sg.off + (int64_t)i * sg.ld + sg.col0 + kr];
@@ -190,11 +191,12 @@ __global__ void k_chain_wexp(PackTable tab, const float* params, int* wexp) {
         if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) wexp[blockIdx.x] = scale_exp(red[0]);
+    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(wmax + blockIdx.x, __float_as_uint(red[0]));
 }
 
+// wexp: [0, 32) the exponents the chain kernels read (written here), [32, 64) the maxima k_chain_wexp gathered
 template <int NP>
-__global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* out, const int* wexp) {
+__global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* out, int* wexp) {
     constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT, PER = Cfg<NP>::PER;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
@@ -216,6 +218,11 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
     }
     const int p = f % NP;
     const int step = (chunk - L.chunk0) * PER + f / NP;  // k-step major, tile minor
+    int wex = 0;
+    if constexpr (NP == 2) {
+        wex = scale_exp(__uint_as_float(reinterpret_cast<const uint32_t*>(wexp)[32 + li]));
+        if (chunk == L.chunk0 && f == 0 && lane == 0) wexp[li] = wex;
+    }
     unsigned short o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (step < L.KS * L.NT) {
         const int ks = step / L.NT, tt = step % L.NT;
@@ -233,7 +240,7 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
                 }
             unsigned short bits;
             if constexpr (NP == 2) {  // fp16 pair of the scaled weight
-                const float t = ldexpf(x, wexp[li]);
+                const float t = ldexpf(x, wex);
                 const _Float16 hh = (_Float16)t;
                 const _Float16 r = p == 0 ? hh : (_Float16)(t - (float)hh);
                 __builtin_memcpy(&bits, &r, 2);
@@ -1847,11 +1854,11 @@ static PackTable bwd_table(int nc) {
 template <int NP>
 static constexpr int64_t chain_bytes() { return (int64_t)(fwd_chunk0<NP>(F_COUNT) + bwd_chunk0<NP>(B_COUNT)) * Cfg<NP>::SLOT; }
 constexpr int64_t WEXP_BYTES = 256;
-static_assert((F_COUNT + B_COUNT) * 4 <= WEXP_BYTES, "wexp table");
+static_assert(F_COUNT + B_COUNT <= 32, "wexp table: 32 exponents + 32 maxima");
 template <int NP>
 static int pack_chain(const PackTable& T, const float* params, unsigned char* out, int* wexp, hipStream_t s) {
     if (NP == 2) {
-        hipLaunchKernelGGL(k_chain_wexp, dim3(T.n), dim3(256), 0, s, T, params, wexp);
+        hipLaunchKernelGGL(k_chain_wexp, dim3(T.n, WEXP_SLICES), dim3(256), 0, s, T, params, reinterpret_cast<uint32_t*>(wexp) + 32);
         PN_CHECK_LAUNCH();
     }
     const int64_t threads = (int64_t)T.nchunks * (Cfg<NP>::CF + 1) * 64;
@@ -1862,7 +1869,7 @@ static int pack_chain(const PackTable& T, const float* params, unsigned char* ou
 template <int NP>
 static int pack_both(int nc, const float* params, unsigned char* out, hipStream_t s) {
     int* wexp = reinterpret_cast<int*>(out + chain_bytes<NP>());
-    if (NP != 2 && hipMemsetAsync(wexp, 0, WEXP_BYTES, s) != hipSuccess) return PN_ERR_HIP;  // (unused: keep the blob defined)
+    if (hipMemsetAsync(wexp, 0, WEXP_BYTES, s) != hipSuccess) return PN_ERR_HIP;  // (maxima start at 0; NP != 2: unused)
     int rc = pack_chain<NP>(fwd_table<NP>(nc), params, out, wexp, s);
     if (rc != PN_OK) return rc;
     return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, wexp + F_COUNT, s);

@@ -150,7 +150,9 @@ def _chain_backward(ev, cfg, params, pack, d_raw_rgb, d_raw_den, v, d_mean, st):
     T32 tensors the weight-gradient GEMMs read on `ev`."""
     dev = d_raw_rgb.device
     e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    # drgb / d8 / coef hold a padded k-step that the 32-sample build (pn_chain_tile() = 32) writes only half of; the
+    # default 16-sample kernels write every feature of every padded row themselves (0.3 ms of fills per step)
+    z = e if _lib.load().pn_chain_tile() == 16 else (lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev))
     Mp = ev.Mp
     sdot = None
     ev.edot = ev.tang = ev.coef = None
