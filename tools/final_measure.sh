@@ -13,6 +13,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt 
 echo "kernel trace done"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-inference > $O/pmc_f.json 2> $O/pmc_f.err
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-inference > $O/pmc_w.json 2> $O/pmc_w.err
+cd $R && tools/pmc_pass.sh sq 2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT
 echo "pmc done"
 cd $R
 timeout -k 10 200 python3 bench.py --global-batch 512 --steps 20 --warmup 5 --no-cpu-baseline --no-inference > $O/bench_b512.json 2> $O/bench_b512.err
