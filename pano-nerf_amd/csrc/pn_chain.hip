@@ -1,4 +1,4 @@
-// pn_chain.hip — the radiance MLP as FUSED on-chip chains on the bf16 matrix cores (gfx950).
+// pn_chain.hip — the radiance MLP as FUSED on-chip chains on the 16-bit (bf16 / fp16) matrix cores (gfx950).
 //
 // Orientation.  Every layer is computed transposed: H_out^T [features x samples] = W [features x K] * H_in^T
 // [K x samples] on the bf16 MFMA.  An accumulator tile then holds one SAMPLE per lane column and FEATURES in its
@@ -24,6 +24,9 @@
 //
 // Arithmetic.  NP = 3: every fp32 operand is split exactly into three bf16 terms (x = h + m + l) and a product is
 // accumulated in fp32 from its six partial products of weight >= 2^-16 (the error is that of an fp32 fma chain);
+// NP = 2 (the default mode): every fp32 operand times a power of two as an fp16 pair, x 2^e = h + l (|error| < 2^-24 |x|),
+// three partial products; the powers of two - one per weight matrix, one per SAMPLE in the chains, one per tensor in the
+// weight-gradient GEMMs - keep fp16 in range and are undone exactly (see chain_gemm, split_into, ex_of, k_chain_wgrad);
 // NP = 1: plain bf16 operands, fp32 accumulate (BASELINE configs[1]).
 //
 // Reference lines replaced: MLP.forward models/pano_mip_nerf.py:95-114 (PureMLP models/mip_nerf.py:81-102),

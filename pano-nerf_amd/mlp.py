@@ -122,7 +122,9 @@ class RadianceMLP(torch.nn.Module):
 
     def chain_packed(self, stream, planes):
         """Fragment-ordered bf16 planes of every weight matrix, in both directions, for the fused chain kernels
-        (pn_chain_pack: one launch, ~7 MB written); rebuilt on every call for the same reason as `packed`."""
+        (pn_chain_pack: ~3-7 MB written); rebuilt on every call for the same reason as `packed`.  The rebuild is IN PLACE on
+        the caller's stream: code that runs forwards on several streams at once builds the pack once before the fork and
+        sets `_frozen` for the duration (parallel.concurrent_step, renderer.render_image)."""
         flat = self.flat_params()
         buf = self._chain.get(planes)
         if buf is None or buf.device != flat.device:

@@ -28,21 +28,36 @@ def render_image(model, rays, env_rays, height, width, chunk_size=32768, white_b
     dev0 = flat.origins.device
     cur = torch.cuda.current_stream(dev0) if dev0.type == "cuda" else None
     lanes = [cur]
-    if cur is not None and streams > 1 and len(mine) > 1:
+    forked = cur is not None and streams > 1 and len(mine) > 1
+    if forked:
+        # The packed weight copies are built ONCE, before the fork, and frozen for the chunk loop: every forward otherwise
+        # rebuilds them in place on its own stream while the other stream's kernels read them (the fp16-pair pack passes
+        # through a cleared table of weight maxima on the way: a chunk rendered during another's re-pack came out as 1e20)
         from .parallel import _streams
-        model.mlp.packed(cur.cuda_stream)  # weight copies are built once, before the fork
+        from .render import _planes_of
+        planes = _planes_of(model.mlp_mode)
+        model.mlp._frozen = False
+        if planes:
+            model.mlp.chain_packed(cur.cuda_stream, planes)
+        else:
+            model.mlp.packed(cur.cuda_stream)
+        model.mlp._frozen = True
         lanes += _streams(dev0, min(int(streams), len(mine)) - 1)
         for s in lanes[1:]:
             s.wait_stream(cur)
-    with torch.no_grad():
-        for n, i in enumerate(mine):
-            lane = lanes[n % len(lanes)]
-            with (torch.cuda.stream(lane) if lane is not None else torch.no_grad()):
-                (c_rgb, c_dep, *_), (f_rgb, f_dep, _, f_nor, alb, _, sf_rgb, _, sd) = model(
-                    rays=chunks[i], env_rays=env_rays, randomized=False, white_bkgd=white_bkgd, enable_surf=True,
-                    use_ort_loss=True)
-                for k, v in zip(outs, (c_rgb, f_rgb, c_dep.view(-1, 1), f_dep.view(-1, 1), f_nor, alb, sf_rgb, sd)):
-                    outs[k].append(v)
+    try:
+        with torch.no_grad():
+            for n, i in enumerate(mine):
+                lane = lanes[n % len(lanes)]
+                with (torch.cuda.stream(lane) if lane is not None else torch.no_grad()):
+                    (c_rgb, c_dep, *_), (f_rgb, f_dep, _, f_nor, alb, _, sf_rgb, _, sd) = model(
+                        rays=chunks[i], env_rays=env_rays, randomized=False, white_bkgd=white_bkgd, enable_surf=True,
+                        use_ort_loss=True)
+                    for k, v in zip(outs, (c_rgb, f_rgb, c_dep.view(-1, 1), f_dep.view(-1, 1), f_nor, alb, sf_rgb, sd)):
+                        outs[k].append(v)
+    finally:
+        if forked:
+            model.mlp._frozen = False
     for s in lanes[1:]:
         cur.wait_stream(s)
     widths_all = dict(coarse_rgb=3, fine_rgb=3, coarse_dep=1, fine_dep=1, fine_nor=3, albedo=3, surface_rgb=3, shading=3)
