@@ -717,7 +717,8 @@ __device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB]
 // (Measured: these one-dword-per-feature stores cost 15-21 % of a chain kernel's time, PN_ABL_CHAIN bit 4 - and a
 // [feature / 4][sample][4] layout with one 16-byte store per quad block, 1 KB contiguous per wave instruction, gained only
 // 0-4 % while the weight-gradient GEMM, which then needs transposing fragment reads, lost 19 %: the cost is the written
-// bytes, not the instruction count.)
+// bytes, not the instruction count.  Nor their burstiness: handing a vector's 64 stores to the NEXT layer's GEMM, one per
+// step behind its MFMAs, left k_chain_dgrad<2> at 1.77 ms (1.79).)
 template <int NT>
 __device__ __forceinline__ void store_t(float* base, const accv (&acc)[NT]) {
     if constexpr (PN_ABL_CHAIN & 16) return;  // (timing ablation: no T stores)
