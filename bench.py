@@ -340,13 +340,20 @@ def main():
                         "algorithmic_bytes_per_launch": fl / max(n, 1) / (2.0 * 256 * 256) * 4.0 * 512}
         bound = "hbm" if (roof_hbm and roof_hbm["frac"] > roof_mfma["frac"]) else "mfma"
         top = roof_hbm if bound == "hbm" else roof_mfma
-        traffic = None
+        traffic, pmc_tab = None, {}
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json" if fused else "r01_pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                pmc_tab = json.load(open(pmc))
+                traffic = pmc_tab.get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, pmc_tab = None, {}
+
+        def hbm_rate(k, avg_us):
+            """HBM GB/s of kernel k: PMC bytes per launch (profiles/r02_pmc_summary.json, same workload) / live duration;
+            only at the profiled size (4096 rays on one GPU)."""
+            b = pmc_tab.get(k, {}).get("hbm_bytes_per_launch") if (world == 1 and args.global_batch == 4096) else None
+            return None if not b else b / max(avg_us, 1e-9) / 1e3
         out = {
             "metric": "rays/sec (train step)", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -403,7 +410,9 @@ def main():
                          "flop_per_launch": fl / max(n, 1),
                          "other": {k: {"total_ms": v[0], "launches": v[1], "avg_launch_us": 1e3 * v[0] / max(v[1], 1),
                                        "tflops": v[2] / max(v[0], 1e-9) / 1e9,
-                                       "frac": v[2] / max(v[0], 1e-9) / 1e9 / peak_of(k)} for k, v in prof.items()},
+                                       "frac": v[2] / max(v[0], 1e-9) / 1e9 / peak_of(k),
+                                       "hbm_gbs_from_pmc_traffic": hbm_rate(k, 1e3 * v[0] / max(v[1], 1))}
+                                   for k, v in prof.items()},
                          "end_to_end_frac": value / world * flop_per_ray_step(args.samples) /
                                             ((peak_chain if fused else PEAK_F32_MFMA_TFLOPS) * 1e12),
                          "end_to_end_frac_of_fp32_mfma_peak": value / world * flop_per_ray_step(args.samples) /

@@ -1539,6 +1539,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
 // [plane][feature][16 samples] images (the two 16-B pieces of a row swapped on features with bit 3 set: conflict-free
 // for the writes and for the ds_read_b128 fragment reads); two LDS buffers, one barrier per half block.  Row sums of X
 // (bias gradients) are accumulated from the fp32 values on the way in.
+// (Tried: one 256 x 352 tile for layer 5 over [h4 | enc] and one 288 x 256 tile for [extra ; density] over h7, so that
+// delta_5 and h7 are read once - 12 accumulator tiles per wave at two waves per SIMD spill 180-280 bytes per lane and the
+// weight gradients of an evaluation took 7.2 ms instead of 5.0: the re-reads, 3 GB per step, stay.)
 struct WSeg {
     const float* X;  // feature 0 of the X sub-range in block 0
     const float* Y;
