@@ -502,6 +502,14 @@ struct GemmStep {
         } else if constexpr (!(PN_ABL_CHAIN & 4)) {
             acc[t] = mfma_split<NP>(q[0], b[ks], acc[t]);
         }
+#ifdef PN_ABL_FILL  // timing experiment: PN_ABL_FILL independent VALU instructions behind every step's MFMAs
+        {
+            float f0 = __int_as_float(lane), f1 = f0;
+#pragma unroll
+            for (int k = 0; k < PN_ABL_FILL; ++k) asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(f0) : "v"(f1));
+            asm volatile("" ::"v"(f0));
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         piece_step<NP, S, S0 + LA, BIASNEXT>(R);
         if constexpr (U == 2) piece_step<NP, S, S0 + LA + 1, BIASNEXT>(R);
