@@ -482,7 +482,7 @@ __device__ __forceinline__ void mfma_pair(const BFrag<2>& a0, const BFrag<2>& a1
 // unit S0 .. S0 + U - 1 of a GEMM of KS x NT steps (k-step major): q[0..U) hold its fragments, q[U..] those of the steps
 // after it; the fragments of steps S0 + LA .. are read before the unit's MFMAs, across chunk boundaries too; the unit then
 // issues the shares of the refill round that those look-ahead positions stand for.
-template <int NP, int KS, int NT, int S0, bool BIASNEXT>
+template <int NP, int KS, int NT, int S0, bool BIASNEXT, bool ZERO = false>
 struct GemmStep {
     static constexpr int LA = Look<NP>::N, U = Unit<NP, NT>::U;
     static_assert(LA >= U && LA % U == 0 && (KS * NT) % U == 0, "look-ahead in whole units");
@@ -500,7 +500,14 @@ struct GemmStep {
             tie<NP>(q[1]);
             mfma_pair(q[0], q[1], b[ks], acc[t], acc[t + 1]);
         } else if constexpr (!(PN_ABL_CHAIN & 4)) {
-            acc[t] = mfma_split<NP>(q[0], b[ks], acc[t]);
+            if constexpr (ZERO && ks == 0) {  // first k-step of a sum that starts at zero: C is the inline constant, not 64 v_mov
+                accv z;
+#pragma unroll
+                for (int e = 0; e < ACCR; ++e) z[e] = 0.f;
+                acc[t] = mfma_split<NP>(q[0], b[ks], z);
+            } else {
+                acc[t] = mfma_split<NP>(q[0], b[ks], acc[t]);
+            }
         }
 #ifdef PN_ABL_FILL  // timing experiment: PN_ABL_FILL independent VALU instructions behind every step's MFMAs
         {
@@ -519,7 +526,7 @@ struct GemmStep {
             for (int i = 0; i + U < LA; ++i) q[i] = q[i + U];
 #pragma unroll
             for (int u = 0; u < U; ++u) q[LA - U + u] = nw[u];
-            GemmStep<NP, KS, NT, S0 + U, BIASNEXT>::run(R, b, acc, sa, q, lane);
+            GemmStep<NP, KS, NT, S0 + U, BIASNEXT, ZERO>::run(R, b, acc, sa, q, lane);
         }
     }
 };
@@ -557,10 +564,7 @@ __device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS]
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not see the asm reads that follow
     } else if constexpr (ZERO) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < ACCR; ++e) acc[t][e] = 0.f;
+        // (the first k-step's products take C = 0: see GemmStep)
     } else if constexpr (NP == 2) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -573,7 +577,7 @@ __device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS]
     uint32_t sa = s0 + lane * 16;
     BFrag<NP> q[Look<NP>::N];
     gemm_prologue<NP, KS * NT, 0, BIASNEXT>(R, sa, q);
-    GemmStep<NP, KS, NT, 0, BIASNEXT>::run(R, b, acc, sa, q, lane);
+    GemmStep<NP, KS, NT, 0, BIASNEXT, ZERO>::run(R, b, acc, sa, q, lane);
     if constexpr (NP == 2) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
