@@ -36,6 +36,7 @@
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -164,14 +165,17 @@ struct PackTable {
 };
 
 // NP = 2 only: one power-of-two scale per packed GEMM, 2^wexp, that takes the largest |weight| of its segments into
-// [2^14, 2^15) (fp16 holds 65504).  The exponent is capped at +40 (a tensor of zeros or of values below 2^-25: scaled sums
-// and the bias that joins them stay far inside fp32's range); large values are never capped - they scale down.  One
-// workgroup per GEMM of the table.
-constexpr int EXP_TOP = 15;   // frexp exponent of the scaled maximum
-constexpr int EXP_CAP = 40;
-__device__ __forceinline__ int scale_exp(float amax) {
+// [2^14, 2^15) (fp16 holds 65504).  Exponents are capped from above only - +30 for a weight matrix, +80 for a sample's
+// vector or a tensor (zeros, or magnitudes below 2^-66 = 1.4e-20, which then lose precision gradually): a bias enters a
+// sum as bias * 2^(wexp + bex) and must stay inside fp32's range; large values are never capped, they scale down.
+constexpr int EXP_TOP = 15;    // frexp exponent of the scaled maximum
+constexpr int EXP_CAP = 80;    // samples / tensors of the forward chain (its sums start from a bias)
+constexpr int EXP_CAP_W = 30;  // weight matrices
+constexpr int EXP_CAP_Z = 120; // samples / tensors of the backward-direction chains and of the weight gradients: their sums
+                               // start at zero, so only the operands' own range matters (deltas of 1e-30 keep full precision)
+__device__ __forceinline__ int scale_exp(float amax, int cap = EXP_CAP) {
     const int e = EXP_TOP - __builtin_amdgcn_frexp_expf(amax);
-    return e > EXP_CAP ? EXP_CAP : e;
+    return e > cap ? cap : e;
 }
 constexpr int WEXP_SLICES = 16;  // workgroups per GEMM of the table (one alone took 67 us on the transposed 256 x 352 matrix)
 __global__ void k_chain_wexp(PackTable tab, const float* params, uint32_t* wmax) {
@@ -223,7 +227,7 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
     const int step = (chunk - L.chunk0) * PER + f / NP;  // k-step major, tile minor
     int wex = 0;
     if constexpr (NP == 2) {
-        wex = scale_exp(__uint_as_float(reinterpret_cast<const uint32_t*>(wexp)[32 + li]));
+        wex = scale_exp(__uint_as_float(reinterpret_cast<const uint32_t*>(wexp)[32 + li]), EXP_CAP_W);
         if (chunk == L.chunk0 && f == 0 && lane == 0) wexp[li] = wex;
     }
     unsigned short o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -639,10 +643,10 @@ __device__ __forceinline__ uint32_t row_umax(uint32_t v) {
     return v;
 }
 // column maximum -> the operand's exponent (the column's maximum goes to [2^14, 2^15)) + the wave's maximum
-__device__ __forceinline__ Ex ex_of(float lane_max) {
+__device__ __forceinline__ Ex ex_of(float lane_max, int cap = EXP_CAP) {
     const float cm = col_max(lane_max);
     Ex e;
-    e.ex = scale_exp(cm);
+    e.ex = scale_exp(cm, cap);
     uint32_t v = row_umax(__float_as_uint(cm));
     if constexpr (NG == 2) {  // 32 sample columns: two rows of 16
         const uint32_t o = (uint32_t)__shfl_xor((int)v, 16, 64);
@@ -717,11 +721,11 @@ __device__ __forceinline__ void split_acc(const accv (&acc)[NT], BFrag<NP> (&b)[
 }
 // Returns the operand's exponent (NP = 2; `also`: largest |x| of further elements the caller appends to the operand).
 template <int NP, int NT, int KB>
-__device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB], float also = 0.f) {
+__device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB], float also = 0.f, int cap = EXP_CAP) {
     constexpr int KS = NT * ACCQ / 2;
     static_assert((NT * ACCQ) % 2 == 0 && KS <= KB, "quad blocks");
     Ex e{0, 0u};
-    if constexpr (NP == 2) e = ex_of(fmaxf(lane_amax<NT>(acc), also));
+    if constexpr (NP == 2) e = ex_of(fmaxf(lane_amax<NT>(acc), also), cap);
     split_acc<NP, NT, KB>(acc, b, e.ex);
     return e;
 }
@@ -942,7 +946,7 @@ __device__ __forceinline__ Ex encode(const float (&mu)[3], const float (&cv)[3],
             for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(x[qb][i]));
-            e = ex_of(m);
+            e = ex_of(m, EXP_CAP_Z);
         }
     }
 #pragma unroll
@@ -956,7 +960,7 @@ __device__ __forceinline__ Ex encode(const float (&mu)[3], const float (&cv)[3],
 }
 // B operand k-steps <- a stored T-layout block of this wave (fp32): the encoding for the skip columns, r5 / delta5
 template <int NP, int KS>
-__device__ __forceinline__ int reload_b(const float* src, BFrag<NP> (&b)[KS]) {
+__device__ __forceinline__ int reload_b(const float* src, BFrag<NP> (&b)[KS], int cap = EXP_CAP) {
     if constexpr (NP == 2) {  // all values first: the exponent comes from their maximum
         float x[KS][8];
         float m = 0.f;
@@ -967,7 +971,7 @@ __device__ __forceinline__ int reload_b(const float* src, BFrag<NP> (&b)[KS]) {
                 x[ks][j] = src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];
                 m = fmaxf(m, fabsf(x[ks][j]));
             }
-        const int ex = scale_exp(col_max(m));
+        const int ex = scale_exp(col_max(m), cap);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) split_into<NP>(x[ks], b[ks], ex);
         return ex;
@@ -1013,7 +1017,7 @@ template <int NP>
 __device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, float* out, BFrag<NP> (&bh)[KS_H]) {
     gate_bits<NT_H>(acc, m);
     if (out) store_t<NT_H>(out, acc);  // (wave-uniform)
-    return acc_to_b<NP, NT_H, KS_H>(acc, bh);
+    return acc_to_b<NP, NT_H, KS_H>(acc, bh, 0.f, EXP_CAP_Z);  // (backward-direction and tangent sweeps only)
 }
 
 // ------------------------------------------------------------------------------------------------- forward chain
@@ -1256,7 +1260,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(a.wd0 + QB * qb + 4 * T.g);
                     wm = fmaxf(fmaxf(wm, fmaxf(fabsf(wv[0]), fabsf(wv[1]))), fmaxf(fabsf(wv[2]), fabsf(wv[3])));
                 }
-                const Ex e = ex_of(sgm * wm);
+                const Ex e = ex_of(sgm * wm, EXP_CAP_Z);
                 bex = e.ex;
                 RM.upd(7, e.top);
             }
@@ -1289,7 +1293,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         {  // d sigma / d enc over [r_0 | r_5] (two accumulating GEMMs: B_DENC0, B_DENC1), then the encoding's adjoint
             accv a3[NT_ENC];
             chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane, wx(B_DENC0) + bex);
-            bex = reload_b<NP, KS_H>(a.vec_t + (a.keep_all ? (int64_t)5 * Mp * 256 : 0) + T.blk * (256 * TILE) + T.lo, bh);
+            bex = reload_b<NP, KS_H>(a.vec_t + (a.keep_all ? (int64_t)5 * Mp * 256 : 0) + T.blk * (256 * TILE) + T.lo, bh, EXP_CAP_Z);
             chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane, wx(B_DENC1) + bex);
             float dm[3];
             ipe_backward_tiles(a3, mu, cv, T.g, dm);
@@ -1358,7 +1362,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
         {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L5) + bex);
             BFrag<NP> benc[KS_ENC];
-            const int eex = reload_b<NP, KS_ENC>(et, benc);
+            const int eex = reload_b<NP, KS_ENC>(et, benc, EXP_CAP_Z);
             chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane, wx(F_L5E) + eex);
             e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
             bex = e.ex;
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
         {
             gate_bits<NT_H>(acc, pop_front(mk));
             store_t<NT_H>(a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, acc);
-            if constexpr (NP == 2) RM.upd(7, ex_of(lane_amax<NT_H>(acc)).top);
+            if constexpr (NP == 2) RM.upd(7, ex_of(lane_amax<NT_H>(acc), EXP_CAP_Z).top);
             float sd = 0.f;
 #pragma unroll
             for (int qb = 0; qb < NT_H * ACCQ; ++qb) {
@@ -1449,7 +1453,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
                 m = fmaxf(m, fabsf(x[j]));
             }
             if constexpr (NP == 2) {
-                e = ex_of(m);
+                e = ex_of(m, EXP_CAP_Z);
                 bex = e.ex;
                 RM.upd(11, e.top);
             }
@@ -1461,7 +1465,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
             chain_gemm<NP, 1, NT_C, false, true>(R, b1, av, lane, wx(B_COLOR) + bex);
             gate_bits<NT_C>(av, pop_front(mk));
             store_t<NT_C>(a.dhv_t + T.blk * (128 * TILE) + T.lo, av);
-            e = acc_to_b<NP, NT_C, KS_C>(av, bc);
+            e = acc_to_b<NP, NT_C, KS_C>(av, bc, 0.f, EXP_CAP_Z);
             bex = e.ex;
             RM.upd(10, e.top);
         }
@@ -1486,8 +1490,8 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
                 m = fmaxf(m, fabsf(v));
             }
             if constexpr (NP == 2) {  // one exponent for the whole operand, separate maxima for the two T tensors
-                e = ex_of(lane_amax<NT_H>(acc));
-                const Ex ed = ex_of(m);
+                e = ex_of(lane_amax<NT_H>(acc), EXP_CAP_Z);
+                const Ex ed = ex_of(m, EXP_CAP_Z);
                 RM.upd(8, e.top);
                 RM.upd(9, ed.top);
                 bex = e.ex < ed.ex ? e.ex : ed.ex;
@@ -1525,7 +1529,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
             }
             accv a3[NT_ENC];
             chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane, wx(B_DENC0) + bex);
-            bex = reload_b<NP, KS_H>(a.delta_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            bex = reload_b<NP, KS_H>(a.delta_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh, EXP_CAP_Z);
             chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane, wx(B_DENC1) + bex);
             float dm[3];
             ipe_backward_tiles(a3, mu, cv, T.g, dm);
@@ -1616,15 +1620,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < LX; ++i) bsum[i] = 0.f;
 
-    // two register sets: the loads of half block h + 2 are issued when h's set has been staged, so they have two half
-    // blocks of MFMA time to land (one workgroup per CU: nothing else hides the HBM latency)
-    f32x4 xr[2][LX], yr[2][LY];
-    float bw[2] = {0.f, 0.f};  // bias weight of the half block held in each set
+    // NSET register sets: the loads of half block h + NSET are issued when h's set has been staged, so they have NSET
+    // half blocks to land (one workgroup per CU: nothing else hides the HBM latency).  Three where the registers allow:
+    // with three products per fp32 product the kernel is HBM-bound and two sets keep only 32-64 KB per CU in flight.
+    constexpr int NSET = (NP <= 2 && LX + LY <= 4) ? 3 : 2;
+    f32x4 xr[NSET][LX], yr[NSET][LY];
+    float bw[NSET] = {};  // bias weight of the half block held in each set
     // NP = 2: exponents of the half block held in each register set, unit (sum of both) of each LDS buffer and of the
     // accumulators: a workgroup whose range crosses into a segment with other scales re-bases its accumulators (exact)
-    int sx[2] = {0, 0}, sy[2] = {0, 0}, ubuf[2] = {0, 0}, unit = 0;
+    int sx[NSET] = {}, sy[NSET] = {}, ubuf[2] = {0, 0}, unit = 0;
     bool first = true;
-    auto load = [&](int64_t h, int set) {
+    auto load = [&](int64_t h, int set) __attribute__((always_inline)) {
         int sg = 0;
         int64_t hb = h;
 #pragma unroll
@@ -1636,8 +1642,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         const WSeg& S = a.seg[sg];
         bw[set] = S.bias ? 1.f : 0.f;
         if constexpr (NP == 2) {
-            sx[set] = scale_exp(__uint_as_float(*S.ax));
-            sy[set] = scale_exp(__uint_as_float(*S.ay));
+            sx[set] = scale_exp(__uint_as_float(*S.ax), EXP_CAP_Z);
+            sy[set] = scale_exp(__uint_as_float(*S.ay), EXP_CAP_Z);
         }
         const int64_t blk = hb / (TILE / 16);  // a T-layout sample block holds TILE / 16 half blocks
         const int half = (int)(hb % (TILE / 16));
@@ -1690,7 +1696,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             }
         }
     };
-    auto stage = [&](int buf, int set) {
+    auto stage = [&](int buf, int set) __attribute__((always_inline)) {
         unsigned short* xs = smem + buf * BUF;
         unsigned short* ys = xs + NP * PX;
 #pragma unroll
@@ -1712,7 +1718,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     auto frag = [&](const unsigned short* plane, int feature) {
         return *reinterpret_cast<const typename PlaneOf<NP>::type*>(plane + feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3));
     };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned short* xs = smem + buf * BUF;
         const unsigned short* ys = xs + NP * PX;
         if constexpr (NP == 2) {
@@ -1747,19 +1753,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split32<NP>(af[i], bf, acc[i][j]);
         }
     };
-    if (h0 < h1) {
-        load(h0, 0);
-        if (h0 + 1 < h1) load(h0 + 1, 1);
-        for (int64_t h = h0; h < h1; h += 2) {  // two half blocks per trip: static register-set / buffer indices
-            stage(0, 0);
+    // half block h + K of a trip: register set K % NSET, LDS buffer K % 2 (static indices)
+    auto one = [&](auto kc, int64_t h) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
+        if (h + K < h1) {  // (uniform)
+            stage(K % 2, K % NSET);
             __syncthreads();
-            if (h + 2 < h1) load(h + 2, 0);
-            compute(0);
-            if (h + 1 < h1) {
-                stage(1, 1);
-                __syncthreads();
-                if (h + 3 < h1) load(h + 3, 1);
-                compute(1);
+            if (h + K + NSET < h1) load(h + K + NSET, K % NSET);
+            compute(K % 2);
+        }
+    };
+    if (h0 < h1) {
+#pragma unroll
+        for (int k = 0; k < NSET; ++k)
+            if (h0 + k < h1) load(h0 + k, k);
+        constexpr int TRIP = NSET == 3 ? 6 : 2;
+        for (int64_t h = h0; h < h1; h += TRIP) {
+            one(std::integral_constant<int, 0>{}, h);
+            one(std::integral_constant<int, 1>{}, h);
+            if constexpr (TRIP == 6) {
+                one(std::integral_constant<int, 2>{}, h);
+                one(std::integral_constant<int, 3>{}, h);
+                one(std::integral_constant<int, 4>{}, h);
+                one(std::integral_constant<int, 5>{}, h);
             }
         }
     }
