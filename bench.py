@@ -329,15 +329,16 @@ def main():
         ms, n, fl = prof[dom]
         avg_us = 1e3 * ms / max(n, 1)
         achieved = fl / max(ms, 1e-9) / 1e9  # TFLOP/s  (FLOP / ms / 1e9)
-        # The 256x256 weight-gradient GEMM reads 4 (256 + 256) bytes per sample row for 2 * 256 * 256 FLOP: with three
+        # The 256x256 weight-gradient GEMM reads 4 (256 + 256) bytes per sample row (2 with bf16 tensors) for 2 * 256 * 256 FLOP: with three
         # partial products per fp32 product it sits nearer the HBM roof than the MFMA one.  Both fractions are reported; `bound`
         # (and the top-level achieved / peak / unit / frac) name the roof the kernel is closer to.
         roof_mfma = {"achieved": achieved, "peak": peak_of(dom), "unit": "TFLOP/s", "frac": achieved / peak_of(dom)}
         roof_hbm = None
         if dom.startswith("k_chain_wgrad") and dom.endswith("2, 4, 4, 2>"):
-            gbs = fl / (2.0 * 256 * 256) * 4.0 * 512 / max(ms, 1e-9) / 1e6  # algorithmic bytes / time, GB/s
+            esz = 2.0 if args.mlp_mode == "fused_bf16" else 4.0  # bytes per element of the sample tensors in this mode
+            gbs = fl / (2.0 * 256 * 256) * esz * 512 / max(ms, 1e-9) / 1e6  # algorithmic bytes / time, GB/s
             roof_hbm = {"achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS,
-                        "algorithmic_bytes_per_launch": fl / max(n, 1) / (2.0 * 256 * 256) * 4.0 * 512}
+                        "algorithmic_bytes_per_launch": fl / max(n, 1) / (2.0 * 256 * 256) * esz * 512}
         bound = "hbm" if (roof_hbm and roof_hbm["frac"] > roof_mfma["frac"]) else "mfma"
         top = roof_hbm if bound == "hbm" else roof_mfma
         traffic, pmc_tab = None, {}

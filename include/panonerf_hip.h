@@ -177,11 +177,13 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_dens
  * accuracy); planes = 2: fp16 pairs (x 2^e = h + l, |error| < 2^-24 |x|), three partial products, one power-of-two scale
  * per weight matrix and per sample (chains) or per tensor (weight gradients), fp32 accumulate; planes = 1: plain bf16
  * operands, fp32 accumulate.  Sample-row tensors these kernels exchange are in the "T layout":
- * float[Mp/tile][F][tile] (sample-minor, tile = pn_chain_tile(), Mp = pn_pad_rows(M)); gate words are uint32 [9][Mp][8]
+ * elem[Mp/tile][F][tile] (sample-minor, tile = pn_chain_tile(), Mp = pn_pad_rows(M)), elem = float for planes 3 and 2,
+ * bf16 for planes = 1 (the stored value is the bf16 the next GEMM consumes: the float* parameters below then point at
+ * 2-byte elements, and a buffer sized in floats is twice as large as needed); gate words are uint32 [9][Mp][8]
  * (per row: tile-dependent lane-group order, see pn_chain.hip; producers and consumers are all in this library). */
 /* samples per block of the sample-minor tensors (= samples per wave of the chain kernels): 16 (v_mfma_f32_16x16x32_bf16,
  * two waves per SIMD; the build default) or 32 (v_mfma_f32_32x32x16_bf16, -DPN_CHAIN_TILE=32).  Below, "T layout" means
- * float[Mp / tile][F][tile]. */
+ * elem[Mp / tile][F][tile]. */
 int pn_chain_tile(void);
 int64_t pn_chain_pack_bytes(int planes);
 int pn_chain_pack(const float* params, int num_density_channels, int planes, void* pack, void* stream);

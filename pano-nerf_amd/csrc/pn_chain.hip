@@ -90,6 +90,18 @@ struct Cfg {
     static constexpr int LDS_BYTES = SLOT * NSLOT;
 };
 
+// Element type of the T tensors: fp32, except with plain bf16 operands (NP = 1), where the value that is stored is the
+// very bf16 the next GEMM and the weight-gradient GEMM consume - storing it in 2 bytes loses nothing and halves the HBM
+// traffic of a mode that is HBM-bound.
+template <int NP>
+struct TEl {
+    typedef float type;
+};
+template <>
+struct TEl<1> {
+    typedef __bf16 type;
+};
+#define TP(p) reinterpret_cast<TE*>(p)  // a T-tensor pointer of an argument struct as its element type (TE: per kernel)
 template <int NP>
 struct PlaneOf {
     typedef bf16x8 type;
@@ -735,13 +747,16 @@ __device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB]
 // 0-4 % while the weight-gradient GEMM, which then needs transposing fragment reads, lost 19 %: the cost is the written
 // bytes, not the instruction count.  Nor their burstiness: handing a vector's 64 stores to the NEXT layer's GEMM, one per
 // step behind its MFMAs, left k_chain_dgrad<2> at 1.77 ms (1.79).)
-template <int NT>
-__device__ __forceinline__ void store_t(float* base, const accv (&acc)[NT]) {
+template <int NT, typename TE>
+__device__ __forceinline__ void store_t(TE* base, const accv (&acc)[NT]) {
     if constexpr (PN_ABL_CHAIN & 16) return;  // (timing ablation: no T stores)
 #pragma unroll
     for (int qb = 0; qb < NT * ACCQ; ++qb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) base[(QB * qb + i) * TILE] = AQ(acc, qb, i);
+        for (int i = 0; i < 4; ++i) {
+            const float x = AQ(acc, qb, i);
+            base[(QB * qb + i) * TILE] = (TE)x;
+        }
 }
 
 // ReLU gate bits of a lane: bit 4 qb + i, (NT * ACCQ) / 8 words (up to 4).  Seen from the B operand, the 8 elements of
@@ -900,8 +915,9 @@ __device__ __forceinline__ Tile tile_of(int64_t st, int wid, int lane, int64_t M
 // integrated positional encoding (MODE 0), or its tangent along v (MODE 1), of this lane's 96 / NG features -> T-layout
 // store + B operand.  Features f and f + 48 (sine / "cosine" of the same argument) sit in the same lane.
 template <int NP, int MODE>
-__device__ __forceinline__ Ex encode(const float (&mu)[3], const float (&cv)[3], const float (&vv)[3], int g, float* et,
-                                      BFrag<NP> (&benc)[KS_ENC]) {
+__device__ __forceinline__ Ex encode(const float (&mu)[3], const float (&cv)[3], const float (&vv)[3], int g,
+                                      typename TEl<NP>::type* et, BFrag<NP> (&benc)[KS_ENC]) {
+    typedef typename TEl<NP>::type TE;
     constexpr int NQ = 96 / QB;  // quad blocks of the encoding; the first half are the sines
     float x[NQ][4];
     const int g4 = 4 * opaque(g);
@@ -933,7 +949,7 @@ __device__ __forceinline__ Ex encode(const float (&mu)[3], const float (&cv)[3],
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) et[(QB * qb + i) * TILE] = x[qb][i];
+        for (int i = 0; i < 4; ++i) et[(QB * qb + i) * TILE] = (TE)x[qb][i];
     if (MODE == 0) TRX(32);
     Ex e{0, 0u};
     if constexpr (NP == 2) {
@@ -960,7 +976,7 @@ __device__ __forceinline__ Ex encode(const float (&mu)[3], const float (&cv)[3],
 }
 // B operand k-steps <- a stored T-layout block of this wave (fp32): the encoding for the skip columns, r5 / delta5
 template <int NP, int KS>
-__device__ __forceinline__ int reload_b(const float* src, BFrag<NP> (&b)[KS], int cap = EXP_CAP) {
+__device__ __forceinline__ int reload_b(const typename TEl<NP>::type* src, BFrag<NP> (&b)[KS], int cap = EXP_CAP) {
     if constexpr (NP == 2) {  // all values first: the exponent comes from their maximum
         float x[KS][8];
         float m = 0.f;
@@ -968,7 +984,7 @@ __device__ __forceinline__ int reload_b(const float* src, BFrag<NP> (&b)[KS], in
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                x[ks][j] = src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];
+                x[ks][j] = (float)src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];
                 m = fmaxf(m, fabsf(x[ks][j]));
             }
         const int ex = scale_exp(col_max(m), cap);
@@ -980,7 +996,7 @@ __device__ __forceinline__ int reload_b(const float* src, BFrag<NP> (&b)[KS], in
         for (int ks = 0; ks < KS; ++ks) {
             float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];  // + 4 g rows via the lane offset
+            for (int j = 0; j < 8; ++j) x[j] = (float)src[(QB * (2 * ks + (j >> 2)) + (j & 3)) * TILE];  // + 4 g rows via the lane offset
             split_into<NP>(x, b[ks]);
         }
         return 0;
@@ -1014,7 +1030,7 @@ __device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], co
 }
 // gate, T-layout store and next B operand of a 256-wide hidden vector (backward-direction sweeps and the tangent sweep)
 template <int NP>
-__device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, float* out, BFrag<NP> (&bh)[KS_H]) {
+__device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, typename TEl<NP>::type* out, BFrag<NP> (&bh)[KS_H]) {
     gate_bits<NT_H>(acc, m);
     if (out) store_t<NT_H>(out, acc);  // (wave-uniform)
     return acc_to_b<NP, NT_H, KS_H>(acc, bh, 0.f, EXP_CAP_Z);  // (backward-direction and tangent sweeps only)
@@ -1045,6 +1061,7 @@ __host__ __device__ constexpr int64_t acts_floats(int64_t Mp) { return 8 * Mp * 
 template <int NP>
 __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    typedef typename TEl<NP>::type TE;  // element type of the T tensors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
@@ -1055,7 +1072,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         TR(0);
-        float* et = a.enc_t + T.blk * (96 * TILE) + T.lo;
+        TE* et = TP(a.enc_t) + T.blk * (96 * TILE) + T.lo;
         BFrag<NP> bh[KS_H];
         accv acc[NT_H];
         Gate mw;
@@ -1085,7 +1102,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         }
         auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T store, next B operand
             relu_bits<NT_H>(acc, mw);
-            if (a.acts_t) store_t<NT_H>(a.acts_t + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);  // (uniform)
+            if (TP(a.acts_t)) store_t<NT_H>(TP(a.acts_t) + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);  // (uniform)
             store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
             const Ex e = acc_to_b<NP, NT_H, KS_H>(acc, bh);
             bex = e.ex;
@@ -1134,7 +1151,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         {
             chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_EXTRA) + bex);
             TR(19);
-            float* bt = a.acts_t ? a.acts_t + act_off(8, Mp) + T.blk * (288 * TILE) + T.lo : nullptr;
+            TE* bt = a.acts_t ? TP(a.acts_t) + act_off(8, Mp) + T.blk * (288 * TILE) + T.lo : nullptr;
             if (bt) store_t<NT_H>(bt, acc);
             const Ex e = acc_to_b<NP, NT_H, KS_H + KS_PAD>(acc, bv, 1.0f);  // the view encoding appended below is <= 1
             vex = e.ex;
@@ -1158,7 +1175,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
                     const float sv = fast_sin(half ? xb + HALF_PI_F : xb);
                     const float o = v < 3 ? sel3(vd, v) : (v < PN_VIEW_DIM ? sv : 0.f);
                     x[j] = o;
-                    if (bt) bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = o;
+                    if (bt) bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = (TE)o;
                 }
                 split_into<NP>(x, bv[KS_H + q], vex);
             }
@@ -1172,7 +1189,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
             TR(21);
             Gate w4;
             relu_bits<NT_C>(av, w4);
-            if (a.acts_t) store_t<NT_C>(a.acts_t + act_off(9, Mp) + T.blk * (128 * TILE) + T.lo, av);
+            if (TP(a.acts_t)) store_t<NT_C>(TP(a.acts_t) + act_off(9, Mp) + T.blk * (128 * TILE) + T.lo, av);
             store_gate(a.masks, 8, Mp, T.blk * TILE + T.c, T.g, w4);
             const Ex e = acc_to_b<NP, NT_C, KS_C>(av, bc);
             cex = e.ex;
@@ -1225,6 +1242,7 @@ struct SweepArgs {
 template <int NP>
 __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    typedef typename TEl<NP>::type TE;  // element type of the T tensors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
@@ -1251,7 +1269,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
             else return 0;
         };
         {  // seed r_7
-            float* rt = a.keep_all ? a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo : nullptr;
+            TE* rt = a.keep_all ? TP(a.vec_t) + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo : nullptr;
             const Gate m7 = pop_front(mk);
             if constexpr (NP == 2) {  // |r_7| <= softplus'(z) * max |Wd[0]| over this lane's features
                 float wm = 0.f;
@@ -1275,7 +1293,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
                         const int j = 4 * h + i;
                         const uint32_t bit = (m7.w[(8 * ks + j) >> 5] >> ((8 * ks + j) & 31)) & 1u;
                         x[j] = bit ? sgm * wv[i] : 0.f;
-                        if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = x[j];
+                        if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = (TE)x[j];
                     }
                 }
                 split_into<NP>(x, bh[ks], bex);
@@ -1285,7 +1303,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
-            float* dst = a.keep_all ? a.vec_t + (int64_t)(l - 1) * Mp * 256 : (l - 1 == 5 ? a.vec_t : nullptr);
+            TE* dst = a.keep_all ? TP(a.vec_t) + (int64_t)(l - 1) * Mp * 256 : (l - 1 == 5 ? TP(a.vec_t) : nullptr);
             const Ex e = finish_gated<NP>(acc, pop_front(mk), dst ? dst + T.blk * (256 * TILE) + T.lo : nullptr, bh);
             bex = e.ex;
             RM.upd(l - 1, e.top);
@@ -1293,7 +1311,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         {  // d sigma / d enc over [r_0 | r_5] (two accumulating GEMMs: B_DENC0, B_DENC1), then the encoding's adjoint
             accv a3[NT_ENC];
             chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane, wx(B_DENC0) + bex);
-            bex = reload_b<NP, KS_H>(a.vec_t + (a.keep_all ? (int64_t)5 * Mp * 256 : 0) + T.blk * (256 * TILE) + T.lo, bh, EXP_CAP_Z);
+            bex = reload_b<NP, KS_H>(TP(a.vec_t) + (a.keep_all ? (int64_t)5 * Mp * 256 : 0) + T.blk * (256 * TILE) + T.lo, bh, EXP_CAP_Z);
             chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane, wx(B_DENC1) + bex);
             float dm[3];
             ipe_backward_tiles(a3, mu, cv, T.g, dm);
@@ -1314,6 +1332,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
 template <int NP>
 __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    typedef typename TEl<NP>::type TE;  // element type of the T tensors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
@@ -1327,7 +1346,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
         Gate mk[8];
 #pragma unroll
         for (int l = 0; l < 8; ++l) mk[l] = load_gate(a.masks, l, Mp, T.blk * TILE + T.c, T.g);
-        float* et = a.edot_t + T.blk * (96 * TILE) + T.lo;
+        TE* et = TP(a.edot_t) + T.blk * (96 * TILE) + T.lo;
         BFrag<NP> bh[KS_H];
         accv acc[NT_H];
         int bex = 0;
@@ -1349,13 +1368,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
             RM.upd(8, e.top);
             chain_gemm<NP, KS_ENC, NT_H, false, true>(R, benc, acc, lane, wx(F_L0) + bex);
         }
-        e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + T.blk * (256 * TILE) + T.lo, bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + T.blk * (256 * TILE) + T.lo, bh);
         bex = e.ex;
         RM.upd(0, e.top);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L0 + l) + bex);
-            e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)l * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)l * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
             bex = e.ex;
             RM.upd(l, e.top);
         }
@@ -1364,18 +1383,18 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
             BFrag<NP> benc[KS_ENC];
             const int eex = reload_b<NP, KS_ENC>(et, benc, EXP_CAP_Z);
             chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane, wx(F_L5E) + eex);
-            e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
             bex = e.ex;
             RM.upd(5, e.top);
         }
         chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L6) + bex);
-        e = finish_gated<NP>(acc, pop_front(mk), a.vec_t + (int64_t)6 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)6 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
         bex = e.ex;
         RM.upd(6, e.top);
         chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L7) + bex);
         {
             gate_bits<NT_H>(acc, pop_front(mk));
-            store_t<NT_H>(a.vec_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, acc);
+            store_t<NT_H>(TP(a.vec_t) + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, acc);
             if constexpr (NP == 2) RM.upd(7, ex_of(lane_amax<NT_H>(acc), EXP_CAP_Z).top);
             float sd = 0.f;
 #pragma unroll
@@ -1421,6 +1440,7 @@ struct BwdArgs {
 template <int NP>
 __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    typedef typename TEl<NP>::type TE;  // element type of the T tensors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
@@ -1443,13 +1463,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
         };
         {
             float x[8];
-            float* dt = a.drgb_t + T.blk * (32 * TILE) + T.lo;
+            TE* dt = TP(a.drgb_t) + T.blk * (32 * TILE) + T.lo;
             float m = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int f = QB * (j >> 2) + 4 * T.g + (j & 3);
                 x[j] = (T.live && f < 3) ? a.d_rgb[T.rc * 3 + (f < 3 ? f : 0)] : 0.f;
-                dt[(QB * (j >> 2) + (j & 3)) * TILE] = x[j];
+                dt[(QB * (j >> 2) + (j & 3)) * TILE] = (TE)x[j];
                 m = fmaxf(m, fabsf(x[j]));
             }
             if constexpr (NP == 2) {
@@ -1464,7 +1484,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
             accv av[NT_C];
             chain_gemm<NP, 1, NT_C, false, true>(R, b1, av, lane, wx(B_COLOR) + bex);
             gate_bits<NT_C>(av, pop_front(mk));
-            store_t<NT_C>(a.dhv_t + T.blk * (128 * TILE) + T.lo, av);
+            store_t<NT_C>(TP(a.dhv_t) + T.blk * (128 * TILE) + T.lo, av);
             e = acc_to_b<NP, NT_C, KS_C>(av, bc, 0.f, EXP_CAP_Z);
             bex = e.ex;
             RM.upd(10, e.top);
@@ -1474,7 +1494,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
         accv acc[NT_H];
         {
             chain_gemm<NP, KS_C, NT_H, false, true>(R, bc, acc, lane, wx(B_VIEW) + bex);
-            float* bt = a.d8_t + T.blk * (288 * TILE) + T.lo;
+            TE* bt = TP(a.d8_t) + T.blk * (288 * TILE) + T.lo;
             store_t<NT_H>(bt, acc);
             const float z = a.raw_den[T.rc * a.nc] + a.density_bias;
             const float add0 = (a.sdot && T.live) ? ch_sp_d2(z) * a.sdot[T.rc] : 0.f;
@@ -1486,7 +1506,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
                 float v = 0.f;
                 if (T.live && ch < a.nc) v = a.d_den[T.rc * a.nc + ch] + (ch == 0 ? add0 : 0.f);
                 x[j] = v;
-                bt[(256 + QB * (j >> 2) + (j & 3)) * TILE] = v;
+                bt[(256 + QB * (j >> 2) + (j & 3)) * TILE] = (TE)v;
                 m = fmaxf(m, fabsf(v));
             }
             if constexpr (NP == 2) {  // one exponent for the whole operand, separate maxima for the two T tensors
@@ -1498,25 +1518,25 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
             }
             split_acc<NP, NT_H, KS_H + 1>(acc, be, bex);
             split_into<NP>(x, be[KS_H], bex);
-            if (a.coef_t) {
-                float* ct = a.coef_t + T.blk * (32 * TILE) + T.lo;
+            if (TP(a.coef_t)) {
+                TE* ct = TP(a.coef_t) + T.blk * (32 * TILE) + T.lo;
                 const float cf = T.live ? ch_sp_d1(z) : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int f = QB * (j >> 2) + 4 * T.g + (j & 3);
-                    ct[(QB * (j >> 2) + (j & 3)) * TILE] = f == 0 ? cf : 0.f;
+                    ct[(QB * (j >> 2) + (j & 3)) * TILE] = (TE)(f == 0 ? cf : 0.f);
                 }
             }
         }
         BFrag<NP> bh[KS_H];
         chain_gemm<NP, KS_H + 1, NT_H, false, true>(R, be, acc, lane, wx(B_EXTRA) + bex);
-        e = finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
         bex = e.ex;
         RM.upd(7, e.top);
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
-            e = finish_gated<NP>(acc, pop_front(mk), a.delta_t + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
             bex = e.ex;
             RM.upd(l - 1, e.top);
         }
@@ -1529,7 +1549,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
             }
             accv a3[NT_ENC];
             chain_gemm<NP, KS_H, NT_ENC, false, true>(R, bh, a3, lane, wx(B_DENC0) + bex);
-            bex = reload_b<NP, KS_H>(a.delta_t + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh, EXP_CAP_Z);
+            bex = reload_b<NP, KS_H>(TP(a.delta_t) + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh, EXP_CAP_Z);
             chain_gemm<NP, KS_H, NT_ENC, false, false>(R, bh, a3, lane, wx(B_DENC1) + bex);
             float dm[3];
             ipe_backward_tiles(a3, mu, cv, T.g, dm);
@@ -1599,7 +1619,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NTH = 64 * WM * WN, TMW = 32 * TM * WM, TNW = 32 * TN * WN;
     constexpr int PX = TMW * 16, PY = TNW * 16;     // bf16 elements per plane
     constexpr int BUF = NP * (PX + PY);             // per buffer
-    constexpr int CX = TMW * 4, CY = TNW * 4;       // 16-B pieces per half block
+    typedef typename TEl<NP>::type TE;              // element type of the T tensors (bf16 for NP = 1: staging is a copy)
+    constexpr int PPR = 16 * (int)sizeof(TE) / 16;  // 16-B pieces per row of 16 samples: 4 (fp32) or 2 (bf16)
+    constexpr int SPP = 16 / PPR;                   // samples per piece
+    constexpr int CX = TMW * PPR, CY = TNW * PPR;   // 16-B pieces per half block
     constexpr int LX = (CX + NTH - 1) / NTH, LY = (CY + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1647,20 +1670,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         }
         const int64_t blk = hb / (TILE / 16);  // a T-layout sample block holds TILE / 16 half blocks
         const int half = (int)(hb % (TILE / 16));
-        const float* xb = S.X + blk * ((int64_t)S.FX * TILE) + half * 16;
-        const float* yb = S.Y + blk * ((int64_t)S.FY * TILE) + half * 16;
+        const TE* xb = reinterpret_cast<const TE*>(S.X) + blk * ((int64_t)S.FX * TILE) + half * 16;
+        const TE* yb = reinterpret_cast<const TE*>(S.Y) + blk * ((int64_t)S.FY * TILE) + half * 16;
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
-            if (CX % NTH == 0 || idx < CX) xr[set][i] = *reinterpret_cast<const f32x4*>(xb + (idx >> 2) * TILE + (idx & 3) * 4);
+            if (CX % NTH == 0 || idx < CX) xr[set][i] = *reinterpret_cast<const f32x4*>(xb + (idx / PPR) * TILE + (idx % PPR) * SPP);
         }
 #pragma unroll
         for (int i = 0; i < LY; ++i) {
             const int idx = tid + NTH * i;
-            if (CY % NTH == 0 || idx < CY) yr[set][i] = *reinterpret_cast<const f32x4*>(yb + (idx >> 2) * TILE + (idx & 3) * 4);
+            if (CY % NTH == 0 || idx < CY) yr[set][i] = *reinterpret_cast<const f32x4*>(yb + (idx / PPR) * TILE + (idx % PPR) * SPP);
         }
     };
     auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v, int ex) {
+        if constexpr (NP == 1) {  // the piece already holds 8 bf16 samples of one feature: copy
+            const int f = idx >> 1, q = idx & 1;
+            *reinterpret_cast<f32x4*>(plane0 + f * 16 + ((q ^ ((f >> 3) & 1)) << 3)) = v;
+            return;
+        }
         const int f = idx >> 2, q = idx & 3;
         const int o = f * 16 + (((q >> 1) ^ ((f >> 3) & 1)) << 3) + (q & 1) * 4;
         if constexpr (NP == 2) {
@@ -1704,7 +1732,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             const int idx = tid + NTH * i;
             if (CX % NTH == 0 || idx < CX) {
                 put(xs, PX, idx, xr[set][i], sx[set]);
-                bsum[i] += bw[set] * ((xr[set][i][0] + xr[set][i][1]) + (xr[set][i][2] + xr[set][i][3]));
+                if constexpr (NP == 1) {
+                    const bf16x8 hv = __builtin_bit_cast(bf16x8, xr[set][i]);
+                    float t = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) t += (float)hv[c];
+                    bsum[i] += bw[set] * t;
+                } else {
+                    bsum[i] += bw[set] * ((xr[set][i][0] + xr[set][i][1]) + (xr[set][i][2] + xr[set][i][3]));
+                }
             }
         }
 #pragma unroll
@@ -1795,9 +1831,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         for (int i = 0; i < LX; ++i) {
             float v = bsum[i];
             v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
+            if constexpr (PPR == 4) v += __shfl_xor(v, 2, 64);
             const int idx = tid + NTH * i;
-            if ((idx & 3) == 0 && (CX % NTH == 0 || idx < CX)) out[(int64_t)TMW * TNW + (idx >> 2)] = v;
+            if (idx % PPR == 0 && (CX % NTH == 0 || idx < CX)) out[(int64_t)TMW * TNW + idx / PPR] = v;
         }
     }
 }
@@ -2191,18 +2227,21 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     };
     auto am = [&](int e, int slot) -> const uint32_t* { return ev[e].amax ? ev[e].amax + slot : nullptr; };
     auto mp = [&](int e) { return pn_pad(ev[e].M); };
-    auto act = [&](int e, int slot) { return ev[e].acts_t + act_off(slot, mp(e)); };
+    // the T tensors hold 2-byte elements with planes = 1 (see TEl): offsets are in ELEMENTS of the mode's type
+    const int64_t esz = planes == 1 ? 2 : 4;
+    auto at = [&](const float* p, int64_t elems) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + elems * esz); };
+    auto act = [&](int e, int slot) { return at(ev[e].acts_t, act_off(slot, mp(e))); };
     int rc;
     // trunk layers (layer 5: hidden columns here, skip columns below)
     for (int l = 0; l < 8; ++l) {
         WgJob j{};
         for (int e = 0; e < n; ++e) {
             const int64_t Mp = mp(e);
-            j.seg[j.nseg++] = WSeg{ev[e].delta_t + (int64_t)l * Mp * 256, l == 0 ? ev[e].enc_t : act(e, l - 1), Mp / 16, 256,
+            j.seg[j.nseg++] = WSeg{at(ev[e].delta_t, (int64_t)l * Mp * 256), l == 0 ? ev[e].enc_t : act(e, l - 1), Mp / 16, 256,
                                    l == 0 ? 96 : 256, 1, am(e, AM_DELTA0 + l), am(e, l == 0 ? AM_ENC : AM_ACT0 + l - 1)};
             if (ev[e].rs_t)
-                j.seg[j.nseg++] = WSeg{ev[e].rs_t + (int64_t)l * Mp * 256,
-                                       l == 0 ? ev[e].edot_t : ev[e].tang_t + (int64_t)(l - 1) * Mp * 256, Mp / 16, 256,
+                j.seg[j.nseg++] = WSeg{at(ev[e].rs_t, (int64_t)l * Mp * 256),
+                                       l == 0 ? ev[e].edot_t : at(ev[e].tang_t, (int64_t)(l - 1) * Mp * 256), Mp / 16, 256,
                                        l == 0 ? 96 : 256, 0, am(e, AM_RS0 + l), am(e, l == 0 ? AM_EDOT : AM_TANG0 + l - 1)};
         }
         j.cfg = l == 0 ? 1 : 0;
@@ -2216,10 +2255,10 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
             WgJob k{};
             for (int e = 0; e < n; ++e) {
                 const int64_t Mp = mp(e);
-                k.seg[k.nseg++] = WSeg{ev[e].delta_t + (int64_t)5 * Mp * 256, ev[e].enc_t, Mp / 16, 256, 96, 0,
+                k.seg[k.nseg++] = WSeg{at(ev[e].delta_t, (int64_t)5 * Mp * 256), ev[e].enc_t, Mp / 16, 256, 96, 0,
                                        am(e, AM_DELTA0 + 5), am(e, AM_ENC)};
                 if (ev[e].rs_t)
-                    k.seg[k.nseg++] = WSeg{ev[e].rs_t + (int64_t)5 * Mp * 256, ev[e].edot_t, Mp / 16, 256, 96, 0,
+                    k.seg[k.nseg++] = WSeg{at(ev[e].rs_t, (int64_t)5 * Mp * 256), ev[e].edot_t, Mp / 16, 256, 96, 0,
                                            am(e, AM_RS0 + 5), am(e, AM_EDOT)};
             }
             k.cfg = 1; k.rows = 256; k.cols = 96;
@@ -2235,13 +2274,13 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     }
     {  // density head: d raw_density^T h7 (+ softplus' rows against hdot_7 into row 0)
         WgJob j{};
-        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t + 256 * TILE, act(e, 7), mp(e) / 16, 288, 256, 1, am(e, AM_D8D), am(e, AM_ACT0 + 7)};
+        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{at(ev[e].d8_t, 256 * TILE), act(e, 7), mp(e) / 16, 288, 256, 1, am(e, AM_D8D), am(e, AM_ACT0 + 7)};
         j.cfg = 3; j.rows = nc; j.cols = 256; j.dst = grads + L.wd; j.ldd = 256; j.dbias = grads + L.bd;
         if ((rc = run(j)) != PN_OK) return rc;
         WgJob k{};
         for (int e = 0; e < n; ++e)
             if (ev[e].rs_t)
-                k.seg[k.nseg++] = WSeg{ev[e].coef_t, ev[e].tang_t + (int64_t)7 * mp(e) * 256, mp(e) / 16, 32, 256, 0,
+                k.seg[k.nseg++] = WSeg{ev[e].coef_t, at(ev[e].tang_t, (int64_t)7 * mp(e) * 256), mp(e) / 16, 32, 256, 0,
                                        am(e, AM_COEF), am(e, AM_TANG0 + 7)};
         if (k.nseg) {
             k.cfg = 3; k.rows = 1; k.cols = 256; k.dst = grads + L.wd; k.ldd = 256; k.dbias = nullptr;

@@ -13,12 +13,24 @@ st = lambda: torch.cuda.current_stream().cuda_stream
 E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
 
 
+_PLANES = 3
+
+
+def TS(t):
+    """Flat view of a T tensor in its element type: bf16 with planes = 1 (the buffers are allocated as floats)."""
+    if t.dtype == torch.bfloat16:
+        return t.reshape(-1)
+    return t.reshape(-1).view(torch.bfloat16) if _PLANES == 1 else t.reshape(-1)
+
+
 def t32_to_rows(t, Mp, F):
     tile = int(lib.pn_chain_tile())
-    return t.view(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
+    return TS(t)[:Mp * F].float().reshape(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
 
 
 def run(M, rows_per_ray, planes, nc=5, reps=0):
+    global _PLANES
+    _PLANES = planes
     torch.manual_seed(0)
     import ctypes
     off = (ctypes.c_int64 * 24)()
@@ -60,20 +72,20 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     print(f"M={M} planes={planes}")
     print("  enc      ", rel(t32_to_rows(enc_t, Mp, 96)[:M], enc[:M]))
     for l in range(8):
-        h = t32_to_rows(acts_t[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
+        h = t32_to_rows(TS(acts_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
         print(f"  h{l}       ", rel(h, acts[l, :M]))
-    b = t32_to_rows(acts_t[8 * Mp * 256:8 * Mp * 256 + Mp * 288], Mp, 288)[:M]
+    b = t32_to_rows(TS(acts_t)[8 * Mp * 256:8 * Mp * 256 + Mp * 288], Mp, 288)[:M]
     print("  bott     ", rel(b[:, :256], acts[8, :M]))
     vr = (torch.arange(M, device=dev) // rows_per_ray) % R
     print("  viewenc  ", rel(b[:, 256:283], venc[vr]), float(b[:, 283:].abs().max()))
-    hv = t32_to_rows(acts_t[8 * Mp * 256 + Mp * 288:], Mp, 128)[:M]
+    hv = t32_to_rows(TS(acts_t)[8 * Mp * 256 + Mp * 288:], Mp, 128)[:M]
     print("  hv       ", rel(hv, acts[9, :M, :128]))
     print("  raw_rgb  ", rel(rr2, rr), " raw_den", rel(rd2, rd))
     # gate bits (pn_chain.hip): lane group g = (f % QB) / 4 holds bit 4 (f / QB) + f % 4 of its 8 / NG words
     tile = int(lib.pn_chain_tile()); ng = 64 // tile; qbs = 4 * ng
     bad = 0
     for l in (0, 5, 7):
-        h = t32_to_rows(acts_t[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
+        h = t32_to_rows(TS(acts_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
         for f in (0, 5, 37, 100, 131, 255):
             qb, g, i = f // qbs, (f % qbs) // 4, f % 4
             word = masks_f[l, :M, g * (8 // ng) + ((4 * qb + i) >> 5)].to(torch.int64) & 0xffffffff

@@ -14,9 +14,19 @@ E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
 Z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
 
 
+_PLANES = 3
+
+
+def TS(t):
+    """Flat view of a T tensor in its element type: bf16 with planes = 1 (the buffers are allocated as floats)."""
+    if t.dtype == torch.bfloat16:
+        return t.reshape(-1)
+    return t.reshape(-1).view(torch.bfloat16) if _PLANES == 1 else t.reshape(-1)
+
+
 def t32_to_rows(t, Mp, F):
     tile = int(lib.pn_chain_tile())
-    return t.reshape(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
+    return TS(t)[:Mp * F].float().reshape(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
 
 
 def rel(a, b):
@@ -24,6 +34,8 @@ def rel(a, b):
 
 
 def run(M, rows_per_ray, planes, nc=5, reps=0):
+    global _PLANES
+    _PLANES = planes
     torch.manual_seed(1)
     off = (ctypes.c_int64 * 24)()
     total = lib.pn_param_layout(nc, off)
@@ -90,14 +102,14 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     print(f"M={M} planes={planes}")
     print("  grad_mean ", rel(gmean2, gmean))
     for l in (7, 5, 3, 0):
-        print(f"  r{l}        ", rel(t32_to_rows(rs_t[l], Mp, 256)[:M], rsweep[l, :M]))
+        print(f"  r{l}        ", rel(t32_to_rows(TS(rs_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M], rsweep[l, :M]))
     print("  edot      ", rel(t32_to_rows(edot_t, Mp, 96)[:M], edot[:M]))
     for l in (0, 4, 5, 7):
-        print(f"  hdot{l}     ", rel(t32_to_rows(tang_t[l], Mp, 256)[:M], tbuf[l, :M]))
+        print(f"  hdot{l}     ", rel(t32_to_rows(TS(tang_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M], tbuf[l, :M]))
     d8 = t32_to_rows(d8_t, Mp, 288)[:M]
     print("  d_bott    ", rel(d8[:, :256], dbott[:M]))
     for l in (7, 6, 5, 1, 0):
-        print(f"  delta{l}    ", rel(t32_to_rows(delta_t[l], Mp, 256)[:M], dbuf[l, :M]))
+        print(f"  delta{l}    ", rel(t32_to_rows(TS(delta_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M], dbuf[l, :M]))
     print("  d_mean    ", rel(d_mean2, d_mean))
     # second-order addend and padded tensors
     z = rd2[:, 0] + dbias
