@@ -97,8 +97,8 @@ def cpu_baseline(n_samples, rays_cpu, rgbs_cpu, env_cpu, b_cpu, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-batch", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--height", type=int, default=512)
@@ -107,16 +107,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the full-panorama inference leg (N = 1 only)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step")
+                    help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step; auto = on "
+                         "(eager fallback if capture fails); off: eager launches, per-launch HIP events inside the timed region")
     ap.add_argument("--mlp-mode", choices=("fused", "fused_f16x2", "fused_bf16", "layerwise"),
                     default=os.environ.get("PN_MLP_MODE", DEFAULT_MODE),
                     help="fused_f16x2 (default): on-chip MLP chains, fp16 pairs with power-of-two scaling, 3 partial products "
                          "(fp32-class accuracy); fused: the same kernels with the exact 3-term bf16 split, 6 partial products; "
                          "fused_bf16: plain bf16 operands (BASELINE configs[1]); layerwise: one fp32 GEMM launch per layer")
     ap.add_argument("--streams", default="auto",
-                    help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 2 with <= 2048 "
-                         "rays per GPU (+4 %% at 512..2048 rays: the chains fill each other's bubbles), else 1 (at 4096 rays "
-                         "the gain is 2 %% and one chain keeps the per-launch roofline figures live)")
+                    help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 1: with the "
+                         "three-product kernels and graph replay one chain is as fast or faster at every size (512 rays: "
+                         "138.9 k vs 133.4 k rays/s with two, 2048: 175.3 k vs 160.3 k)")
     ap.add_argument("--overlap", choices=("on", "off"), default="off",
                     help="weight-gradient GEMMs on a side stream (on) or in line on the main stream (off)")
     args = ap.parse_args()
@@ -214,7 +215,7 @@ def main():
         return loss.detach(), outs[1][0].detach(), gt, model.mlp.last_flat_grad
 
     graph = None
-    n_streams = (2 if nb <= 2048 else 1) if args.streams == "auto" else max(1, int(args.streams))
+    n_streams = 1 if args.streams == "auto" else max(1, int(args.streams))
     state = {"streams": n_streams}
 
     def step(i, local=False):
@@ -261,10 +262,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # graph replay pays when the step is launch-latency sensitive: +5 % at 512 rays per GPU, +2 % at 2048, +1.3 % at 4096
-    # (measured after the launch-count reductions); `auto` keeps the 4096-ray single-GPU run eager so that its GEMM
-    # launches are timed live with HIP events inside the timed region
-    use_graph = args.graph == "on" or (args.graph == "auto" and nb <= 2048)
+    # Graph replay: with the three-product kernels the ~700 launches of a step cost 2 ms of host-side gaps even at 4096
+    # rays (163.8 k rays/s eager, 178.0 k replayed; 512 rays: 123.7 k -> 138.9 k), so `auto` replays at every size and falls
+    # back to eager launches if capture fails.  HIP events cannot be recorded inside a replayed graph: the per-launch
+    # roofline figures are then measured on two eager steps right after the timed region (`--graph off` times them live).
+    use_graph = args.graph in ("on", "auto")
     if use_graph:
         try:
             try_capture()
@@ -291,12 +293,14 @@ def main():
     used_graph = graph is not None
     prof = read_prof()
     _lib.load().pn_prof_enable(0)
-    if not prof_live:  # graph mode: measure the per-launch figures on 2 eager steps right after the timed region
+    if not prof_live:  # graph mode: measure the per-launch figures on eager steps right after the timed region
         eager_graph, graph = graph, None
         state["streams"] = 1  # one chain: with concurrent sub-batches a launch's wall duration is not its cost
+        step(args.warmup + args.steps)  # one untimed eager step first (the allocator and the caches settle after the replays)
+        torch.cuda.synchronize()
         _lib.load().pn_prof_enable(1)
-        for i in range(2):
-            step(args.warmup + args.steps + i)
+        for i in range(3):
+            step(args.warmup + args.steps + 1 + i)
         torch.cuda.synchronize()
         prof = read_prof()
         _lib.load().pn_prof_enable(0)
@@ -391,7 +395,7 @@ def main():
                          "traffic": traffic,
                          "avg_launch_us": avg_us, "launches": n,
                          "measured": "HIP events around every GEMM launch " + ("during the timed region" if prof_live else
-                                     "on 2 eager single-chain steps right after the timed region (events cannot be recorded "
+                                     "on 3 eager single-chain steps (after one untimed) right after the timed region (events cannot be recorded "
                                      "inside a replayed graph, and concurrent sub-batches time-share the matrix cores; same "
                                      "kernels; with sub-batches the timed region's GEMMs have 1/streams of these rows)"),
                          "note": ("timed region runs the weight-gradient GEMMs (k_gemm_tn) on a side stream, concurrently "

@@ -27,7 +27,7 @@ def test_two_rank_bench_flow(graph):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong"
     assert out["config"]["rays_per_gpu"] == 128 and out["value"] > 0
-    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert out["roofline"]["bound"] in ("mfma", "hbm") and 0 < out["roofline"]["frac"] < 1
     assert out["roofline"]["kernel"].startswith("k_chain_")
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
 

@@ -9,7 +9,7 @@ cd $R
 timeout -k 10 420 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "default bench done"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-inference > $O/bench_under_rocprof.json 2> $O/kt.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-inference > $O/bench_under_rocprof.json 2> $O/kt.err
 echo "kernel trace done"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-inference > $O/pmc_f.json 2> $O/pmc_f.err
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-inference > $O/pmc_w.json 2> $O/pmc_w.err
