@@ -107,8 +107,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the full-panorama inference leg (N = 1 only)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step; auto = on "
-                         "(eager fallback if capture fails); off: eager launches, per-launch HIP events inside the timed region")
+                    help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step; auto = up "
+                         "to 2048 rays per GPU (eager fallback if capture fails); off: eager launches, per-launch HIP events "
+                         "inside the timed region")
     ap.add_argument("--mlp-mode", choices=("fused", "fused_f16x2", "fused_bf16", "layerwise"),
                     default=os.environ.get("PN_MLP_MODE", DEFAULT_MODE),
                     help="fused_f16x2 (default): on-chip MLP chains, fp16 pairs with power-of-two scaling, 3 partial products "
@@ -116,8 +117,8 @@ def main():
                          "fused_bf16: plain bf16 operands (BASELINE configs[1]); layerwise: one fp32 GEMM launch per layer")
     ap.add_argument("--streams", default="auto",
                     help="sub-batches of a rank's rays run concurrently on this many HIP streams; auto = 1: with the "
-                         "three-product kernels and graph replay one chain is as fast or faster at every size (512 rays: "
-                         "138.9 k vs 133.4 k rays/s with two, 2048: 175.3 k vs 160.3 k)")
+                         "three-product kernels one chain is as fast as two at every size (512 rays: 136.0 k vs 132.7 k "
+                         "rays/s, 1024: 151.4 k vs 153.1 k, 2048: 162.1 k vs 162.3 k)")
     ap.add_argument("--overlap", choices=("on", "off"), default="off",
                     help="weight-gradient GEMMs on a side stream (on) or in line on the main stream (off)")
     args = ap.parse_args()
@@ -262,11 +263,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Graph replay: with the three-product kernels the ~700 launches of a step cost 2 ms of host-side gaps even at 4096
-    # rays (163.8 k rays/s eager, 178.0 k replayed; 512 rays: 123.7 k -> 138.9 k), so `auto` replays at every size and falls
-    # back to eager launches if capture fails.  HIP events cannot be recorded inside a replayed graph: the per-launch
-    # roofline figures are then measured on two eager steps right after the timed region (`--graph off` times them live).
-    use_graph = args.graph in ("on", "auto")
+    # Graph replay pays where the step is launch-latency sensitive: 512 rays per GPU 136.0 k rays/s replayed against 132.8 k
+    # eager, nothing at 1024 / 2048 (151 k / 162 k either way) or 4096 (163 k either way): `auto` replays up to 2048 rays per
+    # GPU and keeps the 4096-ray run eager, so that its launches are timed live with HIP events inside the timed region;
+    # it falls back to eager launches if capture fails.  (Replayed steps had looked up to 17 % faster for a while - the
+    # library cleared two small tables with hipMemsetAsync, whose graph nodes did not reliably run before the kernels that
+    # accumulate into them: the fast runs were the corrupted ones.  The tables are cleared by a kernel now.)
+    use_graph = args.graph == "on" or (args.graph == "auto" and nb <= 2048)
     if use_graph:
         try:
             try_capture()

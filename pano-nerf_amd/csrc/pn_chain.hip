@@ -189,6 +189,17 @@ __device__ __forceinline__ int scale_exp(float amax, int cap = EXP_CAP) {
     const int e = EXP_TOP - __builtin_amdgcn_frexp_expf(amax);
     return e > cap ? cap : e;
 }
+// Clears a small table of words.  A kernel, not hipMemsetAsync: inside a replayed HIP graph the 256-byte memset nodes were
+// not reliably ordered before the kernels that accumulate into the table (512-ray steps came out NaN or with a stale
+// scale table in 4 of 14 runs; never with eager launches).
+__global__ void k_chain_clear(uint32_t* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+static int chain_clear(void* p, int words, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_clear, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(p), words);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
 constexpr int WEXP_SLICES = 16;  // workgroups per GEMM of the table (one alone took 67 us on the transposed 256 x 352 matrix)
 __global__ void k_chain_wexp(PackTable tab, const float* params, uint32_t* wmax) {
     const PackLayer& L = tab.L[blockIdx.x];
@@ -1940,8 +1951,9 @@ static int pack_chain(const PackTable& T, const float* params, unsigned char* ou
 template <int NP>
 static int pack_both(int nc, const float* params, unsigned char* out, hipStream_t s) {
     int* wexp = reinterpret_cast<int*>(out + chain_bytes<NP>());
-    if (hipMemsetAsync(wexp, 0, WEXP_BYTES, s) != hipSuccess) return PN_ERR_HIP;  // (maxima start at 0; NP != 2: unused)
-    int rc = pack_chain<NP>(fwd_table<NP>(nc), params, out, wexp, s);
+    int rc = chain_clear(wexp, (int)(WEXP_BYTES / 4), s);  // (maxima start at 0; NP != 2: unused)
+    if (rc != PN_OK) return rc;
+    rc = pack_chain<NP>(fwd_table<NP>(nc), params, out, wexp, s);
     if (rc != PN_OK) return rc;
     return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, wexp + F_COUNT, s);
 }
@@ -2112,7 +2124,10 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     a.mean = mean; a.cov = cov; a.viewdirs = viewdirs;
     a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
     a.amax = planes == 2 ? amax : nullptr;
-    if (a.amax && hipMemsetAsync(a.amax, 0, AM_COUNT * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return PN_ERR_HIP;
+    if (a.amax) {
+        const int rc = chain_clear(a.amax, AM_COUNT, (hipStream_t)stream);
+        if (rc != PN_OK) return rc;
+    }
     LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, a, (hipStream_t)stream, 2, (double)M * flops_mlp(nc));
 }
 
