@@ -331,6 +331,8 @@ def main():
     value = args.global_batch * args.steps / elapsed
     psnr = pn.loss.hdr_to_ldr_psnr(pred, gt)
 
+    if not bool(torch.isfinite(loss)):  # a step that ran fast on garbage is not a measurement (seen once: see try_capture)
+        raise RuntimeError(f"bench: non-finite loss {float(loss)} after the timed region on rank {rank}")
     if rank == 0:
         dom = max(prof, key=lambda k: prof[k][0])
         ms, n, fl = prof[dom]
