@@ -1,7 +1,8 @@
 #!/bin/bash
+# times the chain kernels of the default library and of every variant build found (tools/build_variant.sh <suffix> <flags>),
+# back to back on one box: pano-nerf_amd/libpanonerf_hip[_<suffix>].so
 cd "$(dirname "$0")/.."
-for v in "" _tile32; do
-  f=pano-nerf_amd/libpanonerf_hip$v.so
+for f in pano-nerf_amd/libpanonerf_hip.so pano-nerf_amd/libpanonerf_hip_*.so; do
   [ -f $f ] || continue
   echo "== $f"
   PN_LIB=$f timeout -k 10 120 python3 tools/check_chain.py 2 2>&1 | grep "fused forward"
