@@ -1080,6 +1080,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
     R.start(a.pack, lds, fwd_chunk0<NP>(F_COUNT), wid, lane, 0);
     RunMax<10> RM;  // activation slots 0..9
     RM.clear();
+    // NP = 2: the weight exponents of this direction, one per lane, fetched once (a load per layer inside the tile loop
+    // brought a vmcnt(0) in front of every GEMM; the other waves covered it, the timings did not move)
+    int wtab = 0;
+    if constexpr (NP == 2) wtab = a.wexp[lane & 15];
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         TR(0);
@@ -1089,7 +1093,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         Gate mw;
         int bex = 0;  // NP = 2: exponent of the B operand in flight
         auto wx = [&](int i) {
-            if constexpr (NP == 2) return a.wexp[i];
+            if constexpr (NP == 2) return __builtin_amdgcn_readlane(wtab, i);
             else return 0;
         };
         {
@@ -1261,6 +1265,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
     RunMax<8> RM;  // r_0..r_7
     RM.clear();
+    // NP = 2: the weight exponents of this direction, one per lane, fetched once (a load per layer inside the tile loop
+    // brought a vmcnt(0) in front of every GEMM; the other waves covered it, the timings did not move)
+    int wtab = 0;
+    if constexpr (NP == 2) wtab = a.wexp[lane & 15];
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         Gate mk[8];  // gates of h7, h6, ..., h0
@@ -1276,7 +1284,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         BFrag<NP> bh[KS_H];
         int bex = 0;
         auto wx = [&](int i) {
-            if constexpr (NP == 2) return a.wexp[i];
+            if constexpr (NP == 2) return __builtin_amdgcn_readlane(wtab, i);
             else return 0;
         };
         {  // seed r_7
@@ -1352,6 +1360,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
     RunMax<9> RM;  // hdot_0..hdot_7, edot
     RM.clear();
     Ex e;
+    // NP = 2: the weight exponents of this direction, one per lane, fetched once (a load per layer inside the tile loop
+    // brought a vmcnt(0) in front of every GEMM; the other waves covered it, the timings did not move)
+    int wtab = 0;
+    if constexpr (NP == 2) wtab = a.wexp[lane & 15];
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         Gate mk[8];
@@ -1362,7 +1374,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
         accv acc[NT_H];
         int bex = 0;
         auto wx = [&](int i) {
-            if constexpr (NP == 2) return a.wexp[i];
+            if constexpr (NP == 2) return __builtin_amdgcn_readlane(wtab, i);
             else return 0;
         };
         {
@@ -1460,6 +1472,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
     RunMax<12> RM;  // delta_0..7, d bottleneck, d raw_density, d view hidden, d rgb
     RM.clear();
     Ex e;
+    // NP = 2: the weight exponents of this direction, one per lane, fetched once (a load per layer inside the tile loop
+    // brought a vmcnt(0) in front of every GEMM; the other waves covered it, the timings did not move)
+    int wtab = 0;
+    if constexpr (NP == 2) wtab = a.wexp[lane & 15];
     for (int64_t st = blockIdx.x; st < a.nst; st += gridDim.x) {
         const Tile T = tile_of(st, wid, lane, a.M);
         Gate mk[9];  // gates of the view hidden, h7, h6, ..., h0
@@ -1469,7 +1485,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
         BFrag<NP> b1[1];
         int bex = 0;
         auto wx = [&](int i) {
-            if constexpr (NP == 2) return a.wexp[i];
+            if constexpr (NP == 2) return __builtin_amdgcn_readlane(wtab, i);
             else return 0;
         };
         {
@@ -1588,7 +1604,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
 // (bias gradients) are accumulated from the fp32 values on the way in.
 // (Tried: one 256 x 352 tile for layer 5 over [h4 | enc] and one 288 x 256 tile for [extra ; density] over h7, so that
 // delta_5 and h7 are read once - 12 accumulator tiles per wave at two waves per SIMD spill 180-280 bytes per lane and the
-// weight gradients of an evaluation took 7.2 ms instead of 5.0: the re-reads, 3 GB per step, stay.)
+// weight gradients of an evaluation took 7.2 ms instead of 5.0: the re-reads, 3 GB per step, stay.
+// Also tried on the 256 x 256 tile (4.85 ms per evaluation as it stands): staging half block h + 1 piecewise between the
+// matrix products of half block h instead of in its own phase in front of the barrier (5.10 ms: the issue port is shared,
+// the loads go out later); refilling each piece's registers as soon as it is converted (6.3 ms: the waits degrade to
+// vmcnt(0)); four register sets in flight instead of three (4.88 ms: depth is not the limit).)
 struct WSeg {
     const float* X;  // feature 0 of the X sub-range in block 0
     const float* Y;
@@ -1664,25 +1684,44 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     // accumulators: a workgroup whose range crosses into a segment with other scales re-bases its accumulators (exact)
     int sx[NSET] = {}, sy[NSET] = {}, ubuf[2] = {0, 0}, unit = 0;
     bool first = true;
+    // Segment cursor of the loads (half blocks are loaded in increasing order): the segment's pointers, widths and
+    // exponents are fetched when the range crosses into it, not per half block - two dependent scalar loads in front of
+    // every half block's global loads otherwise.
+    int csg = 0, cFX = a.seg[0].FX, cFY = a.seg[0].FY, csx = 0, csy = 0;
+    int64_t cbase = 0, cend = a.seg[0].nhalf;
+    const TE* cX = reinterpret_cast<const TE*>(a.seg[0].X);
+    const TE* cY = reinterpret_cast<const TE*>(a.seg[0].Y);
+    float cbw = a.seg[0].bias ? 1.f : 0.f;
+    if constexpr (NP == 2) {
+        csx = scale_exp(__uint_as_float(*a.seg[0].ax), EXP_CAP_Z);
+        csy = scale_exp(__uint_as_float(*a.seg[0].ay), EXP_CAP_Z);
+    }
     auto load = [&](int64_t h, int set) __attribute__((always_inline)) {
-        int sg = 0;
-        int64_t hb = h;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (sg == i && i + 1 < a.nseg && hb >= a.seg[i].nhalf) {
-                hb -= a.seg[i].nhalf;
-                sg = i + 1;
+        while (csg + 1 < a.nseg && h >= cend) {  // (uniform; the last segment takes what is left)
+            ++csg;
+            const WSeg& S = a.seg[csg];
+            cbase = cend;
+            cend += S.nhalf;
+            cX = reinterpret_cast<const TE*>(S.X);
+            cY = reinterpret_cast<const TE*>(S.Y);
+            cFX = S.FX;
+            cFY = S.FY;
+            cbw = S.bias ? 1.f : 0.f;
+            if constexpr (NP == 2) {
+                csx = scale_exp(__uint_as_float(*S.ax), EXP_CAP_Z);
+                csy = scale_exp(__uint_as_float(*S.ay), EXP_CAP_Z);
             }
-        const WSeg& S = a.seg[sg];
-        bw[set] = S.bias ? 1.f : 0.f;
+        }
+        const int64_t hb = h - cbase;
+        bw[set] = cbw;
         if constexpr (NP == 2) {
-            sx[set] = scale_exp(__uint_as_float(*S.ax), EXP_CAP_Z);
-            sy[set] = scale_exp(__uint_as_float(*S.ay), EXP_CAP_Z);
+            sx[set] = csx;
+            sy[set] = csy;
         }
         const int64_t blk = hb / (TILE / 16);  // a T-layout sample block holds TILE / 16 half blocks
         const int half = (int)(hb % (TILE / 16));
-        const TE* xb = reinterpret_cast<const TE*>(S.X) + blk * ((int64_t)S.FX * TILE) + half * 16;
-        const TE* yb = reinterpret_cast<const TE*>(S.Y) + blk * ((int64_t)S.FY * TILE) + half * 16;
+        const TE* xb = cX + blk * ((int64_t)cFX * TILE) + half * 16;
+        const TE* yb = cY + blk * ((int64_t)cFY * TILE) + half * 16;
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
@@ -1937,6 +1976,7 @@ template <int NP>
 static constexpr int64_t chain_bytes() { return (int64_t)(fwd_chunk0<NP>(F_COUNT) + bwd_chunk0<NP>(B_COUNT)) * Cfg<NP>::SLOT; }
 constexpr int64_t WEXP_BYTES = 256;
 static_assert(F_COUNT + B_COUNT <= 32, "wexp table: 32 exponents + 32 maxima");
+static_assert(F_COUNT <= 16 && B_COUNT <= 16, "the chain kernels keep a direction's exponents in lanes 0..15");
 template <int NP>
 static int pack_chain(const PackTable& T, const float* params, unsigned char* out, int* wexp, hipStream_t s) {
     if (NP == 2) {
