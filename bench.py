@@ -157,7 +157,7 @@ def main():
     # names as rocprofv3 prints them (profiles/*_kernel_stats.csv, profiles/r02_pmc_summary.json)
     CLASSES = ((0, "k_gemm_nt"), (1, "k_gemm_tn"), (2, f"k_chain_fwd<{np_}>"), (3, f"k_chain_dgrad<{np_}>"),
                (4, f"k_chain_tangent<{np_}>"), (5, f"k_chain_bwd<{np_}>"), (6, f"k_chain_wgrad<{np_}, 2, 4, 4, 2>"),
-               (7, f"k_chain_wgrad<{np_}, 1, 3, 8, 1>"), (8, f"k_chain_wgrad<{np_}, 1, 9, 4, 1>"),
+               (7, f"k_chain_wgrad<{np_}, 1, 3, 8, 1>"), (8, f"k_chain_wgrad<{np_}, 1, 3, 4, 3>"),
                (9, f"k_chain_wgrad<{np_}, 1, 2, 1, 4>"), (10, f"k_chain_wgrad<{np_}, 1, 1, 1, 4>"))
 
     def read_prof():

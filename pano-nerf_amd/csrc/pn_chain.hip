@@ -2087,8 +2087,11 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     a.half_total = total;
     const int TMW = kCfgM[j.cfg], TNW = kCfgN[j.cfg];
     const int64_t stride = (int64_t)TMW * TNW + TMW;
+    // workgroups per CU the configuration's registers and LDS allow (the narrow tiles: 146 / 100 registers per lane,
+    // 37 / 20 KB): more sample ranges in flight, their staging and product phases interleave
+    static const int kPerCu[5] = {1, 1, 1, 3, 4};
     int cus = chain_cus();
-    int64_t nsplit = cus;
+    int64_t nsplit = (int64_t)cus * kPerCu[j.cfg];
     if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;  // at least four half blocks per workgroup
     if (nsplit < 1) nsplit = 1;
     a.per = (total + nsplit - 1) / nsplit;
@@ -2105,7 +2108,9 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     switch (j.cfg) {
         case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a); break;
         case 1: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 8, 1>), grid, dim3(512), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 9, 4, 1>), grid, dim3(256), 0, s, a); break;
+        // (128 x 288 by twelve waves of 1 x 3 tiles: as four waves of 1 x 9 it held 392 registers per lane - one wave per
+        // SIMD, two register sets in flight - and ran 3.8 TB/s)
+        case 2: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 4, 3>), grid, dim3(768), 0, s, a); break;
         case 3: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 2, 1, 4>), grid, dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 1, 1, 4>), grid, dim3(256), 0, s, a); break;
     }
