@@ -757,7 +757,8 @@ __device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB]
 // [feature / 4][sample][4] layout with one 16-byte store per quad block, 1 KB contiguous per wave instruction, gained only
 // 0-4 % while the weight-gradient GEMM, which then needs transposing fragment reads, lost 19 %: the cost is the written
 // bytes, not the instruction count.  Nor their burstiness: handing a vector's 64 stores to the NEXT layer's GEMM, one per
-// step behind its MFMAs, left k_chain_dgrad<2> at 1.77 ms (1.79).)
+// step behind its MFMAs, left k_chain_dgrad<2> at 1.77 ms (1.79).  Non-temporal stores: forward 2.30 ms (2.36), dgrad 1.83
+// (1.78), tangent 1.70 (1.72), backward unchanged - not adopted.)
 template <int NT, typename TE>
 __device__ __forceinline__ void store_t(TE* base, const accv (&acc)[NT]) {
     if constexpr (PN_ABL_CHAIN & 16) return;  // (timing ablation: no T stores)
@@ -1645,6 +1646,8 @@ __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<N
     }
     return v;
 }
+// the T tensors are read once per GEMM: non-temporal loads (4.70 -> 4.57 ms for the GEMMs of one evaluation)
+#define WG_LD(p) __builtin_nontemporal_load(p)
 template <int NP, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NTH = 64 * WM * WN, TMW = 32 * TM * WM, TNW = 32 * TN * WN;
@@ -1725,12 +1728,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
-            if (CX % NTH == 0 || idx < CX) xr[set][i] = *reinterpret_cast<const f32x4*>(xb + (idx / PPR) * TILE + (idx % PPR) * SPP);
+            if (CX % NTH == 0 || idx < CX) xr[set][i] = WG_LD(reinterpret_cast<const f32x4*>(xb + (idx / PPR) * TILE + (idx % PPR) * SPP));
         }
 #pragma unroll
         for (int i = 0; i < LY; ++i) {
             const int idx = tid + NTH * i;
-            if (CY % NTH == 0 || idx < CY) yr[set][i] = *reinterpret_cast<const f32x4*>(yb + (idx / PPR) * TILE + (idx % PPR) * SPP);
+            if (CY % NTH == 0 || idx < CY) yr[set][i] = WG_LD(reinterpret_cast<const f32x4*>(yb + (idx / PPR) * TILE + (idx % PPR) * SPP));
         }
     };
     auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v, int ex) {
