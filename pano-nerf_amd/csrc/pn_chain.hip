@@ -1173,9 +1173,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
             vex = e.ex;
             RM.upd(8, e.top);
             const int64_t vr = (T.rc / a.rows_per_ray) % a.view_rows;
-            float vd[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) vd[i] = a.viewdirs[vr * 3 + i];
+            // (three scalars, not an array: with `float vd[3]` the selects below became a run-time index into a scratch
+            // copy - eight scratch loads per tile, each behind a vmcnt(0) that also waits for the weight ring's DMA)
+            float vd0 = a.viewdirs[vr * 3], vd1 = a.viewdirs[vr * 3 + 1], vd2 = a.viewdirs[vr * 3 + 2];
+            asm volatile("" : "+v"(vd0), "+v"(vd1), "+v"(vd2));
+            auto vsel = [&](int ch) { return ch == 0 ? vd0 : (ch == 1 ? vd1 : vd2); };
             const int g4 = 4 * opaque(T.g);
 #pragma unroll
             for (int q = 0; q < KS_PAD; ++q) {
@@ -1187,9 +1189,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
                     const int i = v - 3, half = i >= 12 ? 1 : 0;
                     int l, ch;
                     level_of(i < 0 ? 0 : i - 12 * half, l, ch);
-                    const float xb = sel3(vd, ch) * pow2i(l & 3);
+                    const float xb = vsel(ch) * pow2i(l & 3);
                     const float sv = fast_sin(half ? xb + HALF_PI_F : xb);
-                    const float o = v < 3 ? sel3(vd, v) : (v < PN_VIEW_DIM ? sv : 0.f);
+                    const float o = v < 3 ? vsel(v) : (v < PN_VIEW_DIM ? sv : 0.f);
                     x[j] = o;
                     if (bt) bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = (TE)o;
                 }
@@ -1609,7 +1611,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
 // Also tried on the 256 x 256 tile (4.85 ms per evaluation as it stands): staging half block h + 1 piecewise between the
 // matrix products of half block h instead of in its own phase in front of the barrier (5.10 ms: the issue port is shared,
 // the loads go out later); refilling each piece's registers as soon as it is converted (6.3 ms: the waits degrade to
-// vmcnt(0)); four register sets in flight instead of three (4.88 ms: depth is not the limit).)
+// vmcnt(0)); four register sets in flight instead of three (4.88 ms: depth is not the limit).  In fact hipcc drains the
+// prefetched sets in front of every staging phase (vmcnt(3), (2), (1), (0): it cannot count the younger loads behind the
+// conditional `load`); a condition-free steady-state loop with a conditional tail gets vmcnt(13)..(10) - and runs 4.67 ms
+// against 4.57 (two sets; three spill): the loop is bound by its conversion + product instruction time, not by latency.)
 struct WSeg {
     const float* X;  // feature 0 of the X sub-range in block 0
     const float* Y;
