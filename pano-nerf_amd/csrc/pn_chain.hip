@@ -619,16 +619,36 @@ __device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS]
 // --------------------------------------------------------------------------------------------- register plumbing
 // NP = 2: x * 2^ex = h + l in fp16 (11 + 11 significant bits and the sign of l: the error is below 2^-24 |x| while
 // l stays normal, and below 2^-39 of the column's largest element otherwise); NP = 3: x = h + m + l in bf16, exactly.
+// The fp16 pairs of two elements, packed: h = fl16(x s), l = fl16(x s - h) for a power of two s, by mixed-precision FMAs
+// that round once into their half of the destination - two instructions per element where ldexp, convert, convert
+// back, subtract, convert take 3.5 (bit-identical to that sequence up to the sign of a zero; the chain kernels and the
+// weight-gradient GEMMs are bound by their vector + matrix instruction time, and the split is a third of the former).
+__device__ __forceinline__ void split2_pair(float x0, float x1, float s, uint32_t& h, uint32_t& l) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+}
+__device__ __forceinline__ float pow2f(int e) { return __int_as_float((127 + e) << 23); }  // -126 <= e <= 127
 template <int NP>
 __device__ __forceinline__ void split_into(const float (&x)[8], BFrag<NP>& f, int ex = 0) {
+    if constexpr (NP == 2) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const float s = pow2f(ex);  // (ex = min(15 - frexp exponent, cap <= 120) lies in [-113, 120])
+        u32x4 h, l;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if constexpr (NP == 2) {
-            const float t = ldexpf(x[j], ex);
-            const _Float16 h = (_Float16)t;
-            f.p[0][j] = h;
-            f.p[1][j] = (_Float16)(t - (float)h);
-        } else {
+        for (int q = 0; q < 4; ++q) {
+            uint32_t hq, lq;
+            split2_pair(x[2 * q], x[2 * q + 1], s, hq, lq);
+            h[q] = hq;
+            l[q] = lq;
+        }
+        f.p[0] = __builtin_bit_cast(f16x8, h);
+        f.p[1] = __builtin_bit_cast(f16x8, l);
+    }
+    if constexpr (NP != 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
             const __bf16 h = (__bf16)x[j];
             f.p[0][j] = h;
             if constexpr (NP == 3) {
@@ -1750,17 +1770,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         const int f = idx >> 2, q = idx & 3;
         const int o = f * 16 + (((q >> 1) ^ ((f >> 3) & 1)) << 3) + (q & 1) * 4;
         if constexpr (NP == 2) {
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            f16x4 hv, lv;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float t = ldexpf(v[c], ex);
-                const _Float16 hh = (_Float16)t;
-                hv[c] = hh;
-                lv[c] = (_Float16)(t - (float)hh);
-            }
-            *reinterpret_cast<f16x4*>(plane0 + o) = hv;
-            *reinterpret_cast<f16x4*>(plane0 + pstride + o) = lv;
+            const float s = pow2f(ex);
+            uint2 hv, lv;
+            split2_pair(v[0], v[1], s, hv.x, lv.x);
+            split2_pair(v[2], v[3], s, hv.y, lv.y);
+            *reinterpret_cast<uint2*>(plane0 + o) = hv;
+            *reinterpret_cast<uint2*>(plane0 + pstride + o) = lv;
         } else {
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 hv, mv, lv;
