@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the full-panorama inference leg (N = 1 only)")
+    ap.add_argument("--no-cfg2", action="store_true", help="skip the BASELINE configs[1] (256x512, bf16, 512 rays) leg (N = 1 only)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step; auto = up "
                          "to 2048 rays per GPU (eager fallback if capture fails); off: eager launches, per-launch HIP events "
@@ -182,9 +183,12 @@ def main():
         m = torch.eye(4)
         m[:3, 3] = torch.rand(3, generator=gcpu) - 0.5
         cams.append(m.numpy())
+    # no ray pool is stored: a batch is regenerated from (camera, pixel) by pn_sample_pano_rays; only the
+    # target colours live in HBM (the materialised pool below is a temporary to evaluate them once)
     ray_pool = pn.DeviceRayPool(args.height, args.width, cams, near=0.0, far=10.0, device=dev)
     pool = ray_pool.rays
     gt_pool = analytic_radiance(pool.viewdirs, pool.origins)
+    del pool
     ray_pool.rgbs = gt_pool
     env = ray_pool.lit_rays(10)
     n_pool = len(ray_pool)
@@ -217,7 +221,7 @@ def main():
 
     graph = None
     n_streams = 1 if args.streams == "auto" else max(1, int(args.streams))
-    state = {"streams": n_streams}
+    state = {"streams": n_streams, "replay_check": None, "last_g": None}
 
     def step(i, local=False):
         """One training step.  `local=True` (rank-0-only measurement legs after the timed region) skips the gradient
@@ -227,11 +231,13 @@ def main():
             graph.replay()
             loss, pred, gt, g = state["out"]
             if world == 1:
+                state["last_g"] = g
                 return loss, pred, gt  # Adam is part of the graph
         else:
             loss, pred, gt, g = fwd_bwd()
         if world > 1 and not local:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        state["last_g"] = g
         opt.step_dev(g, lr_dev, grad_scale=1.0 if local else 1.0 / world)
         return loss, pred, gt
 
@@ -247,8 +253,6 @@ def main():
                 opt.step_dev(out[3], lr_dev, grad_scale=1.0 / world) if world == 1 else None
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        from pano_nerf_amd.mlp import mark_dirty
-        mark_dirty(model.mlp)  # the weight re-pack must be part of the captured sequence (weights change every step)
         g_ = torch.cuda.CUDAGraph()
         # thread_local: RCCL's helper threads may touch HIP while we capture; they must not invalidate the capture
         with torch.cuda.graph(g_, capture_error_mode="thread_local" if world > 1 else "global"):
@@ -257,6 +261,29 @@ def main():
                 opt.step_dev(out[3], lr_dev, grad_scale=1.0)
         state["out"] = out
         graph = g_
+        # Self-check (the first RCCL run captures with RCCL's helper threads alive): one replay must reproduce one eager
+        # step on the SAME batch - same generator state, hence the same rays and jitter - in loss and flat gradient.  A
+        # mismatch on ANY rank sends every rank back to eager launches (config.launch says so).
+        rng = torch.cuda.get_rng_state(dev)
+        l_e, _, _, g_e = fwd_bwd()
+        l_e, g_e = l_e.clone(), g_e.clone()
+        torch.cuda.set_rng_state(rng, dev)
+        graph.replay()
+        l_g, g_g = state["out"][0], state["out"][3]
+        torch.cuda.synchronize()
+        scale = float(g_e.abs().max())
+        ok = (bool(torch.isfinite(l_g)) and abs(float(l_g) - float(l_e)) <= 1e-6 * abs(float(l_e))
+              and float((g_g - g_e).abs().max()) <= 1e-6 * scale and scale > 0)
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        state["replay_check"] = {"loss_eager": float(l_e), "loss_replay": float(l_g),
+                                 "max_grad_diff_over_max_grad": float((g_g - g_e).abs().max()) / max(scale, 1e-30),
+                                 "ok_all_ranks": bool(flag.item() > 0.5)}
+        if flag.item() < 0.5:
+            print(f"[bench] rank {rank}: a replayed step does not reproduce the eager step "
+                  f"({state['replay_check']}); running eagerly", file=sys.stderr)
+            graph = None
 
     def fence():
         if world > 1:
@@ -294,6 +321,17 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     used_graph = graph is not None
+    # audit trail of the data-parallel step: every rank's ray count and last loss, and the norm of the gradient block as it
+    # stood after the last all-reduce (identical on all ranks by construction; rank 0 reports it)
+    audit = {"rays_per_rank": [nb], "last_loss_per_rank": [float(loss)],
+             "allreduced_grad_l2": float(state["last_g"].double().norm()) if state["last_g"] is not None else None}
+    if world > 1:
+        rec = torch.tensor([float(nb), float(loss), audit["allreduced_grad_l2"] or 0.0], device=dev, dtype=torch.float64)
+        recs = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(recs, rec)
+        audit = {"rays_per_rank": [int(r[0].item()) for r in recs], "last_loss_per_rank": [float(r[1].item()) for r in recs],
+                 "allreduced_grad_l2": float(recs[0][2].item()),
+                 "allreduced_grad_l2_spread_over_ranks": float(max(r[2].item() for r in recs) - min(r[2].item() for r in recs))}
     prof = read_prof()
     _lib.load().pn_prof_enable(0)
     if not prof_live:  # graph mode: measure the per-launch figures on eager steps right after the timed region
@@ -338,26 +376,35 @@ def main():
         ms, n, fl = prof[dom]
         avg_us = 1e3 * ms / max(n, 1)
         achieved = fl / max(ms, 1e-9) / 1e9  # TFLOP/s  (FLOP / ms / 1e9)
-        # The 256x256 weight-gradient GEMM reads 4 (256 + 256) bytes per sample row (2 with bf16 tensors) for 2 * 256 * 256 FLOP: with three
-        # partial products per fp32 product it sits nearer the HBM roof than the MFMA one.  Both fractions are reported; `bound`
-        # (and the top-level achieved / peak / unit / frac) name the roof the kernel is closer to.
-        roof_mfma = {"achieved": achieved, "peak": peak_of(dom), "unit": "TFLOP/s", "frac": achieved / peak_of(dom)}
+        # this path is priced against the MFMA roof.  `achieved` = the 16-bit matrix-core FLOP/s the kernel
+        # ISSUES (algorithmic 2 M N K FLOPs x partial products per fp32 product) against the dense 16-bit peak (2.5 PF);
+        # `algorithmic_tflops` = the fp32-equivalent figure (frac_algorithmic = that / 2.5 PF).  The HBM view of the same
+        # kernel (algorithmic operand bytes / duration against 8 TB/s) is kept as `roofline.hbm`.
+        prod = {3: 6.0, 2: 3.0, 1: 1.0}[np_] if dom.startswith("k_chain") else 1.0
+        peak_dom = PEAK_BF16_MFMA_TFLOPS if dom.startswith("k_chain") else PEAK_F32_MFMA_TFLOPS
+        roof_mfma = {"achieved": achieved * prod, "peak": peak_dom, "unit": "TFLOP/s", "frac": achieved * prod / peak_dom,
+                     "algorithmic_tflops": achieved, "frac_algorithmic": achieved / peak_dom,
+                     "partial_products_per_fp32_product": prod}
         roof_hbm = None
         if dom.startswith("k_chain_wgrad") and dom.endswith("2, 4, 4, 2>"):
+            # the 256 x 256 weight-gradient tile reads 4 (256 + 256) bytes per sample row (2 with bf16 tensors) for 2 * 256 * 256 FLOP
             esz = 2.0 if args.mlp_mode == "fused_bf16" else 4.0  # bytes per element of the sample tensors in this mode
             gbs = fl / (2.0 * 256 * 256) * esz * 512 / max(ms, 1e-9) / 1e6  # algorithmic bytes / time, GB/s
             roof_hbm = {"achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS,
                         "algorithmic_bytes_per_launch": fl / max(n, 1) / (2.0 * 256 * 256) * esz * 512}
-        bound = "hbm" if (roof_hbm and roof_hbm["frac"] > roof_mfma["frac"]) else "mfma"
-        top = roof_hbm if bound == "hbm" else roof_mfma
-        traffic, pmc_tab = None, {}
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json" if fused else "r01_pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                pmc_tab = json.load(open(pmc))
-                traffic = pmc_tab.get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic, pmc_tab = None, {}
+        bound = "mfma"
+        top = roof_mfma
+        traffic, pmc_tab, pmc_src = None, {}, None
+        for cand in (["r03_pmc_summary.json", "r02_pmc_summary.json"] if fused else ["r01_pmc_summary.json"]):
+            pmc = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pmc):
+                try:
+                    pmc_tab = json.load(open(pmc))
+                    traffic = pmc_tab.get(dom, {}).get("hbm_bytes_per_launch")
+                    pmc_src = {"file": "profiles/" + cand, "taken_on": pmc_tab.get("_taken_on"), "note": pmc_tab.get("_note")}
+                    break
+                except Exception:
+                    traffic, pmc_tab, pmc_src = None, {}, None
 
         def hbm_rate(k, avg_us):
             """HBM GB/s of kernel k: PMC bytes per launch (profiles/r02_pmc_summary.json, same workload) / live duration;
@@ -377,7 +424,11 @@ def main():
                                    f"({hi - lo} per GPU)",
                        "global_batch": args.global_batch, "rays_per_gpu": hi - lo, "num_samples": args.samples,
                        "parallelism": f"dp{world} (rays sharded, one 2.455 MB gradient all-reduce/step)",
-                       "launch": "hip-graph replay" if used_graph else "eager",
+                       "launch": ("hip-graph replay" if used_graph else
+                                  ("eager (a replayed step did not reproduce the eager step: fell back)"
+                                   if (state["replay_check"] and not state["replay_check"]["ok_all_ranks"]) else "eager")),
+                       "replay_check": state["replay_check"],
+                       "data_parallel_audit": audit,
                        "schedule": (f"{n_streams} concurrent sub-batches of {(hi - lo + n_streams - 1) // n_streams} rays on "
                                     f"{n_streams} HIP streams per GPU" if n_streams > 1 else "one chain per GPU"),
                        "mlp_mode": args.mlp_mode,
@@ -397,7 +448,7 @@ def main():
                          "peak": top["peak"],
                          "unit": top["unit"], "frac": top["frac"],
                          "mfma": roof_mfma, "hbm": roof_hbm,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": pmc_src,
                          "avg_launch_us": avg_us, "launches": n,
                          "measured": "HIP events around every GEMM launch " + ("during the timed region" if prof_live else
                                      "on 3 eager single-chain steps (after one untimed) right after the timed region (events cannot be recorded "
@@ -407,9 +458,11 @@ def main():
                                   "with the k_gemm_nt chain: per-launch durations include time sharing; `isolated` = the "
                                   "same kernels in 2 extra steps with the side stream off.  " if args.overlap == "on" else
                                   "all launches on one stream (no time sharing between kernels).  ") +
-                                 ("`achieved` and `peak` are fp32-equivalent: algorithmic 2*M*N*K FLOPs per launch against the "
-                                  "dense 16-bit MFMA peak (2.5 PF) divided by the partial products per fp32 product (six for "
-                                  "the bf16 three-term split, three for the fp16 pair)"
+                                 ("top-level `achieved` / `peak` / `frac` are the SURVEY.md 8(d) MFMA figure: 16-bit matrix-core "
+                                  "FLOP/s issued (algorithmic 2*M*N*K FLOPs per launch x partial products per fp32 product: six "
+                                  "for the bf16 three-term split, three for the fp16 pair) against the dense 16-bit MFMA peak "
+                                  "(2.5 PF); `mfma.algorithmic_tflops` is the fp32-equivalent rate; `hbm` is the same kernel's "
+                                  "algorithmic operand bytes against 8 TB/s; `other[*].tflops` are fp32-equivalent"
                                   if args.mlp_mode in ("fused", "fused_f16x2") else
                                   ("`peak` is the dense bf16 MFMA figure (2.5 PF)" if args.mlp_mode == "fused_bf16" else
                                    "`peak` is the 2.4 GHz datasheet figure; under the power cap the same k_gemm_nt binary runs "
@@ -421,10 +474,12 @@ def main():
                          "other": {k: {"total_ms": v[0], "launches": v[1], "avg_launch_us": 1e3 * v[0] / max(v[1], 1),
                                        "tflops": v[2] / max(v[0], 1e-9) / 1e9,
                                        "frac": v[2] / max(v[0], 1e-9) / 1e9 / peak_of(k),
+                                       "frac_is": "fp32-equivalent TFLOP/s over (2.5 PF / partial products) = issued 16-bit FLOP/s over 2.5 PF",
                                        "hbm_gbs_from_pmc_traffic": hbm_rate(k, 1e3 * v[0] / max(v[1], 1))}
                                    for k, v in prof.items()},
                          "end_to_end_frac": value / world * flop_per_ray_step(args.samples) /
                                             ((peak_chain if fused else PEAK_F32_MFMA_TFLOPS) * 1e12),
+                         "end_to_end_frac_is": "rays/s/GPU x 1.696 GFLOP (SURVEY.md 8d) x partial products / 2.5 PF",
                          "end_to_end_frac_of_fp32_mfma_peak": value / world * flop_per_ray_step(args.samples) /
                                                               (PEAK_F32_MFMA_TFLOPS * 1e12)},
             "psnr_batch_db": psnr, "loss": float(loss),
@@ -433,7 +488,7 @@ def main():
             # inference rays/s for one full panorama: the first camera's H x W rays through render_image
             # (normals + env light + surface shading, 32768-ray chunks), after the timed training region
             hw = args.height * args.width
-            cam0 = pn.Rays(*[p[:hw] for p in pool])
+            cam0 = pn.generate_pano_rays(args.height, args.width, cams[0], 0.0, 10.0, device=dev)
             with torch.no_grad():
                 nw = min(4 * 32768, hw)  # warm-up over four chunks: both chunk streams allocate their buffers once
                 pn.render_image(model, pn.Rays(*[p[:nw] for p in cam0]), env, 1, nw, chunk_size=32768)
@@ -444,11 +499,49 @@ def main():
                 dt = time.perf_counter() - t1
             out["inference"] = {"pano": f"{args.height}x{args.width}", "num_samples": args.samples, "chunk_size": 32768,
                                 "seconds_per_pano": dt, "rays_per_s": hw / dt}
+        if world == 1 and not args.no_cfg2:
+            # BASELINE.json configs[1] (panonerf.yaml, 256x512 pano, 128 samples, bf16) on this GPU, after the timed region
+            # and outside `value`: its own 3-camera 256x512 pool, a fresh model in plain-bf16 arithmetic, 512-ray batches
+            # (configs/panonerf.yaml:4), 5 timed eager steps after 2 warm-up steps
+            pool2 = pn.DeviceRayPool(256, 512, cams, near=0.0, far=10.0, device=dev)
+            full2 = pool2.rays
+            pool2.rgbs = analytic_radiance(full2.viewdirs, full2.origins)
+            del full2
+            env2 = pool2.lit_rays(10)
+            torch.manual_seed(4)
+            m2 = pn.PanoMipNeRF(num_samples=128, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5,
+                                num_env_samples=10).to(dev)
+            m2.mlp_mode = "fused_bf16"
+            opt2 = pn.FlatAdam(m2.mlp, lr=2e-4)
+
+            def step2(i):
+                r2, g2 = pool2.sample(512)
+                opt2.zero_grad()
+                o2 = m2(rays=r2, env_rays=env2, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+                l2, _ = pn.pano_loss(o2, r2.lossmult, g2)
+                l2.backward()
+                opt2.step(m2.mlp.last_flat_grad, lr=pn.mip_lr(i))
+                return l2.detach()
+            for i in range(2):
+                step2(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(5):
+                l2 = step2(2 + i)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            if not bool(torch.isfinite(l2)):
+                raise RuntimeError("bench: non-finite loss in the configs[1] (bf16) leg")
+            out["extra"] = {"cfg2_bf16": {"workload": "panonerf.yaml train step, 256x512 pano pool x3 cams, 128 + 128 samples, "
+                                                      "512-ray batches, mlp_mode fused_bf16 (bf16 operands, fp32 accumulate), eager",
+                                          "rays_per_s": 512 * 5 / dt2, "ms_per_step": 1e3 * dt2 / 5, "steps": 5, "warmup": 2,
+                                          "loss": float(l2)}}
+            del m2, opt2, pool2
         if world == 1 and not args.no_cpu_baseline:
             k = args.cpu_rays
-            rays_cpu = pn.Rays(*[x[:k].cpu() for x in pn.Rays(*[p[torch.arange(0, k * 997, 997, device=dev) % n_pool]
-                                                                for p in pool])])
-            gt_cpu = gt_pool[torch.arange(0, k * 997, 997, device=dev) % n_pool].cpu()
+            rays_k, gt_k = ray_pool.take(torch.arange(0, k * 997, 997, device=dev) % n_pool)
+            rays_cpu = pn.Rays(*[x.cpu() for x in rays_k])
+            gt_cpu = gt_k.cpu()
             from oracle import pano_oracle as orc
             env_cpu = orc.Rays(*[x.cpu() for x in env])
             out["cpu_baseline"] = cpu_baseline(args.samples, orc.Rays(*rays_cpu), gt_cpu, env_cpu, k)

@@ -86,6 +86,15 @@ int pn_lit_rays(int D, double radius, double near_, double far_, uint16_t* out_h
 int pn_gather_rays(int64_t B, int64_t pool_rays, const int64_t* idx, const float* const* pool_host,
                    float* const* out_host, void* stream);
 
+/* Training-batch sampler that REGENERATES the rays instead of reading a stored pool (replaces
+ * PanoDataset.__getitem__, datasets/pano_datasets.py:271-275, over the pool of _generate_rays, :152-216): batch ray b is
+ * pixel idx[b] % (H W) of camera idx[b] / (H W), computed with the arithmetic of pn_raygen_pano (bit-identical to a
+ * gather out of its output).  c2ws: DEVICE [n_cam,16] row-major 4x4; rgb_pool [n_cam H W,3] / rgb_out [B,3]: target
+ * colours, both or neither; out-of-range idx reads ray 0. */
+int pn_sample_pano_rays(int64_t B, int n_cam, int H, int W, const int64_t* idx, const float* c2ws, float near_, float far_,
+                        const float* rgb_pool, float* origins, float* directions, float* viewdirs, float* radii,
+                        float* lossmult, float* near_out, float* far_out, float* noise_var, float* rgb_out, void* stream);
+
 /* ---- sampling ----------------------------------------------------------------------
  * sample_along_rays (models/mip.py:113-151, disparity = False) + cast_rays (67-89) +
  * conical_frustum_to_gaussian (36-64, stable) + lift_gaussian (8-22, diagonal).

@@ -24,6 +24,7 @@ SIGNATURES = {
     "pn_raygen_pano": ("i", "iipff" + "p" * 8 + "p"),
     "pn_lit_rays": ("i", "idddpp"),
     "pn_gather_rays": ("i", "llpppp"),
+    "pn_sample_pano_rays": ("i", "liiippffp" + "p" * 9 + "p"),
     "pn_sample_coarse": ("i", "li" + "p" * 9 + "p"),
     "pn_resample": ("i", "lippfp" + "p" * 6 + "p"),
     "pn_sample_env": ("i", "lii" + "p" * 11 + "p"),

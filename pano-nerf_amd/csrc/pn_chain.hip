@@ -1708,10 +1708,28 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NSET = (NP <= 2 && LX + LY <= 4) ? 3 : 2;
     f32x4 xr[NSET][LX], yr[NSET][LY];
     float bw[NSET] = {};  // bias weight of the half block held in each set
-    // NP = 2: exponents of the half block held in each register set, unit (sum of both) of each LDS buffer and of the
-    // accumulators: a workgroup whose range crosses into a segment with other scales re-bases its accumulators (exact)
-    int sx[NSET] = {}, sy[NSET] = {}, ubuf[2] = {0, 0}, unit = 0;
-    bool first = true;
+    // NP = 2: ONE unit for the whole job, 2^unit = the scale of every product in the accumulators: the smallest sx + sy over
+    // the job's segments (the segment with the LARGEST products).  A segment whose own exponents add up to more is scaled
+    // down by the difference (its products are that many binades below the dominant segment's; what falls below fp16's
+    // range there is below 2^-39 of the dominant products) - no accumulator is ever re-based, so sums cannot overflow
+    // however far the segments' magnitudes are apart, and the result does not depend on where a workgroup's range starts.
+    int sx[NSET] = {}, sy[NSET] = {}, unit = 0;
+    auto seg_exps = [&](const WSeg& S, int& ex, int& ey) {
+        ex = scale_exp(__uint_as_float(*S.ax), EXP_CAP_Z);
+        ey = scale_exp(__uint_as_float(*S.ay), EXP_CAP_Z);
+        int over = ex + ey - unit;                      // >= 0
+        const int rx = over < ex + 126 ? over : ex + 126;  // pow2f takes -126 .. 127
+        ex -= rx;
+        ey -= over - rx;
+        if (ey < -126) ey = -126;                       // (everything of the segment has long been flushed to zero)
+    };
+    if constexpr (NP == 2) {
+        unit = 1 << 20;
+        for (int i = 0; i < a.nseg; ++i) {
+            const int e = scale_exp(__uint_as_float(*a.seg[i].ax), EXP_CAP_Z) + scale_exp(__uint_as_float(*a.seg[i].ay), EXP_CAP_Z);
+            unit = e < unit ? e : unit;
+        }
+    }
     // Segment cursor of the loads (half blocks are loaded in increasing order): the segment's pointers, widths and
     // exponents are fetched when the range crosses into it, not per half block - two dependent scalar loads in front of
     // every half block's global loads otherwise.
@@ -1720,10 +1738,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     const TE* cX = reinterpret_cast<const TE*>(a.seg[0].X);
     const TE* cY = reinterpret_cast<const TE*>(a.seg[0].Y);
     float cbw = a.seg[0].bias ? 1.f : 0.f;
-    if constexpr (NP == 2) {
-        csx = scale_exp(__uint_as_float(*a.seg[0].ax), EXP_CAP_Z);
-        csy = scale_exp(__uint_as_float(*a.seg[0].ay), EXP_CAP_Z);
-    }
+    if constexpr (NP == 2) seg_exps(a.seg[0], csx, csy);
     auto load = [&](int64_t h, int set) __attribute__((always_inline)) {
         while (csg + 1 < a.nseg && h >= cend) {  // (uniform; the last segment takes what is left)
             ++csg;
@@ -1735,10 +1750,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             cFX = S.FX;
             cFY = S.FY;
             cbw = S.bias ? 1.f : 0.f;
-            if constexpr (NP == 2) {
-                csx = scale_exp(__uint_as_float(*S.ax), EXP_CAP_Z);
-                csy = scale_exp(__uint_as_float(*S.ay), EXP_CAP_Z);
-            }
+            if constexpr (NP == 2) seg_exps(S, csx, csy);
         }
         const int64_t hb = h - cbase;
         bw[set] = cbw;
@@ -1821,7 +1833,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             const int idx = tid + NTH * i;
             if (CY % NTH == 0 || idx < CY) put(ys, PY, idx, yr[set][i], sy[set]);
         }
-        ubuf[buf] = sx[set] + sy[set];
     };
     const int fr = lane & 31, fh = lane >> 5;
     auto frag = [&](const unsigned short* plane, int feature) {
@@ -1830,24 +1841,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned short* xs = smem + buf * BUF;
         const unsigned short* ys = xs + NP * PX;
-        if constexpr (NP == 2) {
-            if (first) {
-                unit = ubuf[buf];
-                first = false;
-            } else if (ubuf[buf] != unit) {  // (uniform, at most once per segment boundary)
-                const int d = ubuf[buf] - unit;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float x = acc[i][j][e];
-                            acc[i][j][e] = ldexpf(x, d);
-                        }
-                unit = ubuf[buf];
-            }
-        }
         BFrag<NP> af[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -2021,36 +2014,45 @@ static int pack_both(int nc, const float* params, unsigned char* out, hipStream_
     return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, wexp + F_COUNT, s);
 }
 
+// Per-device launch state: the chains need 75 KB of dynamic LDS, an attribute that is set per (kernel, device), and the grid
+// is sized by the device's CU count - a process may drive several devices (one host thread per device).
+constexpr int PN_MAX_DEVICES = 64;
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PN_MAX_DEVICES) dev = 0;
+    return dev;
+}
+struct AttrDone {
+    bool done[PN_MAX_DEVICES];
+};
 template <typename K, typename A>
-static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s, int cls, double flops);
+static int launch_chain(K kernel, int lds_bytes, AttrDone& attr, int64_t nst, const A& a, hipStream_t s, int cls, double flops);
 
-static int g_chain_cus = 0;
-static int chain_cus();
-static int chain_grid(int64_t nst) {
-    if (!g_chain_cus) {
-        int dev = 0;
+static int g_chain_cus[PN_MAX_DEVICES] = {};
+static int chain_cus() {
+    const int dev = current_device();
+    if (!g_chain_cus[dev]) {
         hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) g_chain_cus = 256;
-        else g_chain_cus = pr.multiProcessorCount;
+        g_chain_cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
     }
-    int64_t wgs = (int64_t)g_chain_cus * CH_WG_PER_CU;
+    return g_chain_cus[dev];
+}
+static int chain_grid(int64_t nst) {
+    int64_t wgs = (int64_t)chain_cus() * CH_WG_PER_CU;
 #ifdef PN_TRACE_CHAIN  // diagnostic: PN_TRACE_ONE_WG=1 leaves every SIMD with ONE wave (is a GEMM phase slowed by its neighbour?)
-    if (getenv("PN_TRACE_ONE_WG")) wgs = g_chain_cus;
+    if (getenv("PN_TRACE_ONE_WG")) wgs = chain_cus();
 #endif
     return (int)(nst < wgs ? nst : wgs);
 }
-static int chain_cus() {
-    chain_grid(1);
-    return g_chain_cus;
-}
 
 template <typename K, typename A>
-static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, const A& a, hipStream_t s, int cls, double flops) {
+static int launch_chain(K kernel, int lds_bytes, AttrDone& attr, int64_t nst, const A& a, hipStream_t s, int cls, double flops) {
     PnProfScope prof(cls, flops, s);
-    if (!attr_done) {
+    const int dev = current_device();
+    if (!attr.done[dev]) {  // (two threads racing here both set the same value)
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return PN_ERR_HIP;
-        attr_done = true;
+        attr.done[dev] = true;
     }
     hipLaunchKernelGGL(kernel, dim3(chain_grid(nst)), dim3(CH_THREADS), lds_bytes, s, a);
     PN_CHECK_LAUNCH();
@@ -2058,7 +2060,7 @@ static int launch_chain(K kernel, int lds_bytes, bool& attr_done, int64_t nst, c
 }
 #define LAUNCH_CHAIN(KERNEL, planes, nst, args, s, cls, flops)                                                   \
     do {                                                                                                        \
-        static bool done3 = false, done2 = false, done1 = false;                                                \
+        static AttrDone done3 = {}, done2 = {}, done1 = {};                                                     \
         if ((planes) == 3) return launch_chain(KERNEL<3>, Cfg<3>::LDS_BYTES, done3, nst, args, s, cls, flops);  \
         if ((planes) == 2) return launch_chain(KERNEL<2>, Cfg<2>::LDS_BYTES, done2, nst, args, s, cls, flops);  \
         if ((planes) == 1) return launch_chain(KERNEL<1>, Cfg<1>::LDS_BYTES, done1, nst, args, s, cls, flops);  \

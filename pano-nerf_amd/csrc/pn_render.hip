@@ -68,26 +68,28 @@ __device__ __forceinline__ float group_excl_scan(float v, int gl) {
 }
 
 // --------------------------------------------------------------------------- ray generation
-__global__ void k_raygen_pano(int H, int W, float r00, float r01, float r02, float r10, float r11, float r12,
-                              float r20, float r21, float r22, float tx, float ty, float tz, float near_, float far_,
-                              float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
-                              float* near_out, float* far_out, float* noise_var) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= H * W) return;
-    int i = idx / W, j = idx % W;
+// One pixel of an equirectangular camera (datasets/pano_datasets.py:157-213): shared by the pool generator and by the
+// batch sampler that regenerates rays from (camera, pixel), so that both give the same bits.
+struct PanoCam {
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22, tx, ty, tz;
+};
+struct PanoRay {
+    float d[3], nrm, radius, noise_var;
+};
+__device__ __forceinline__ PanoRay pano_ray(int H, int W, const PanoCam& c, int i, int j) {
     const float PI_F = 3.14159265358979323846f;
     auto cam_dir = [&](int ii, int jj, float out[3]) {
         float theta = -((float)jj + 0.5f) / (float)W * 2.f * PI_F;
         float phi = ((float)ii + 0.5f) / (float)H * PI_F;
         float sp = sinf(phi);
         float x = sp * sinf(theta), y = cosf(phi), z = sp * cosf(theta);
-        out[0] = x * r00 + y * r01 + z * r02;  // camera_dirs @ c2w[:3,:3].T
-        out[1] = x * r10 + y * r11 + z * r12;
-        out[2] = x * r20 + y * r21 + z * r22;
+        out[0] = x * c.r00 + y * c.r01 + z * c.r02;  // camera_dirs @ c2w[:3,:3].T
+        out[1] = x * c.r10 + y * c.r11 + z * c.r12;
+        out[2] = x * c.r20 + y * c.r21 + z * c.r22;
     };
-    float d[3];
-    cam_dir(i, j, d);
-    float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    PanoRay r;
+    cam_dir(i, j, r.d);
+    r.nrm = sqrtf(r.d[0] * r.d[0] + r.d[1] * r.d[1] + r.d[2] * r.d[2]);
     // constant pixel radius: |dir(H/2, jj) - dir(H/2, jj+1)| * 2 / sqrt(12); column W-1 repeats column W-3
     int jj = (j < W - 1) ? j : W - 3;
     if (jj < 0) jj = 0;
@@ -96,19 +98,57 @@ __global__ void k_raygen_pano(int H, int W, float r00, float r01, float r02, flo
     cam_dir(H / 2, jj + 1 < W ? jj + 1 : jj, b);
     float dx = sqrtf((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
     float phi = ((float)i + 0.5f) / (float)H * PI_F;
-    origins[idx * 3 + 0] = tx;
-    origins[idx * 3 + 1] = ty;
-    origins[idx * 3 + 2] = tz;
+    r.radius = (float)((double)dx * 2.0 / sqrt(12.0));
+    r.noise_var = sinf(phi) * PI_F / (float)W;
+    return r;
+}
+__device__ __forceinline__ void store_pano_ray(int64_t o, const PanoRay& r, const PanoCam& c, float near_, float far_,
+                                               float* origins, float* directions, float* viewdirs, float* radii,
+                                               float* lossmult, float* near_out, float* far_out, float* noise_var) {
+    origins[o * 3 + 0] = c.tx;
+    origins[o * 3 + 1] = c.ty;
+    origins[o * 3 + 2] = c.tz;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        directions[idx * 3 + c] = d[c];
-        viewdirs[idx * 3 + c] = d[c] / nrm;
+    for (int k = 0; k < 3; ++k) {
+        directions[o * 3 + k] = r.d[k];
+        viewdirs[o * 3 + k] = r.d[k] / r.nrm;
     }
-    radii[idx] = (float)((double)dx * 2.0 / sqrt(12.0));
-    lossmult[idx] = 1.f;
-    near_out[idx] = near_;
-    far_out[idx] = far_;
-    noise_var[idx] = sinf(phi) * PI_F / (float)W;
+    radii[o] = r.radius;
+    lossmult[o] = 1.f;
+    near_out[o] = near_;
+    far_out[o] = far_;
+    noise_var[o] = r.noise_var;
+}
+
+__global__ void k_raygen_pano(int H, int W, PanoCam c, float near_, float far_,
+                              float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
+                              float* near_out, float* far_out, float* noise_var) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const PanoRay r = pano_ray(H, W, c, idx / W, idx % W);
+    store_pano_ray(idx, r, c, near_, far_, origins, directions, viewdirs, radii, lossmult, near_out, far_out, noise_var);
+}
+
+// Training-batch sampler that REGENERATES the rays: batch ray b is pixel idx[b] % (H W) of camera idx[b] / (H W); only the
+// 12-byte target colour is read from a stored pool (no 56-byte-per-ray pool in HBM, no pool reads).
+__global__ void k_sample_pano_rays(int64_t B, int n_cam, int H, int W, const int64_t* idx, const float* c2ws, float near_,
+                                   float far_, const float* rgb_pool, float* origins, float* directions, float* viewdirs,
+                                   float* radii, float* lossmult, float* near_out, float* far_out, float* noise_var,
+                                   float* rgb_out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t hw = (int64_t)H * W;
+    int64_t r = idx[b];
+    r = (r >= 0 && r < hw * n_cam) ? r : 0;
+    const int cam = (int)(r / hw), pix = (int)(r % hw);
+    const float* m = c2ws + 16 * cam;
+    const PanoCam c{m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10], m[3], m[7], m[11]};
+    const PanoRay ray = pano_ray(H, W, c, pix / W, pix % W);
+    store_pano_ray(b, ray, c, near_, far_, origins, directions, viewdirs, radii, lossmult, near_out, far_out, noise_var);
+    if (rgb_pool) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rgb_out[b * 3 + k] = rgb_pool[r * 3 + k];
+    }
 }
 
 __device__ __forceinline__ uint16_t f64_to_half_bits(double x) {
@@ -1018,9 +1058,22 @@ int pn_raygen_pano(int H, int W, const float* c, float near_, float far_, float*
     if (H <= 0 || W < 3) return PN_ERR_BAD_SHAPE;
     if (!c || !origins || !directions || !viewdirs || !radii || !lossmult || !near_out || !far_out || !noise_var)
         return PN_ERR_NULL;
-    hipLaunchKernelGGL(k_raygen_pano, dim3(nblk((int64_t)H * W, 256)), dim3(256), 0, ST(stream), H, W, c[0], c[1], c[2],
-                       c[4], c[5], c[6], c[8], c[9], c[10], c[3], c[7], c[11], near_, far_, origins, directions,
-                       viewdirs, radii, lossmult, near_out, far_out, noise_var);
+    const PanoCam cam{c[0], c[1], c[2], c[4], c[5], c[6], c[8], c[9], c[10], c[3], c[7], c[11]};
+    hipLaunchKernelGGL(k_raygen_pano, dim3(nblk((int64_t)H * W, 256)), dim3(256), 0, ST(stream), H, W, cam, near_, far_,
+                       origins, directions, viewdirs, radii, lossmult, near_out, far_out, noise_var);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+}
+
+int pn_sample_pano_rays(int64_t B, int n_cam, int H, int W, const int64_t* idx, const float* c2ws, float near_, float far_,
+                        const float* rgb_pool, float* origins, float* directions, float* viewdirs, float* radii,
+                        float* lossmult, float* near_out, float* far_out, float* noise_var, float* rgb_out, void* stream) {
+    if (B <= 0 || n_cam <= 0 || H <= 0 || W < 3) return PN_ERR_BAD_SHAPE;
+    if (!idx || !c2ws || !origins || !directions || !viewdirs || !radii || !lossmult || !near_out || !far_out || !noise_var)
+        return PN_ERR_NULL;
+    if ((rgb_pool == nullptr) != (rgb_out == nullptr)) return PN_ERR_NULL;  // target colours: both or neither
+    hipLaunchKernelGGL(k_sample_pano_rays, dim3(nblk(B, 128)), dim3(128), 0, ST(stream), B, n_cam, H, W, idx, c2ws, near_,
+                       far_, rgb_pool, origins, directions, viewdirs, radii, lossmult, near_out, far_out, noise_var, rgb_out);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }

@@ -57,8 +57,8 @@ class RadianceMLP(torch.nn.Module):
             torch.nn.init.xavier_uniform_(m.weight.data)  # models/pano_mip_nerf.py:10-14; color_layer keeps default
         self._offsets, self._total = None, None
         self.flat = None
-        self._version_packed = None
         self._wpack = None
+        self._generation = 0  # bumped by every writer that bypasses autograd's version counters (FlatAdam: raw pointers)
         self._chain = {}  # planes -> packed chains of the fused kernels (buffer reused, contents rebuilt per call)
         self._frozen = False  # concurrent_step: packs built once before the sub-batch streams fork
         self.last_flat_grad = None
@@ -82,7 +82,6 @@ class RadianceMLP(torch.nn.Module):
             p.data = flat[o:o + p.numel()].view(p.shape)
         self.flat = flat
         self._wpack = None
-        self._version_packed = None
         self._chain = {}
 
     def _apply(self, fn, *a, **kw):
@@ -105,7 +104,12 @@ class RadianceMLP(torch.nn.Module):
         bump them; `p.data.copy_`, raw device writes and collectives do not — hence the packs below are rebuilt on every
         call rather than cached on this key)."""
         flat = self.flat_params()
-        return tuple(p._version for _, p in self.named_in_order()) + (flat._version, flat.data_ptr())
+        return tuple(p._version for _, p in self.named_in_order()) + (flat._version, flat.data_ptr(), self._generation)
+
+    def note_raw_write(self):
+        """A writer that goes through raw device pointers (FlatAdam's kernels) calls this: a backward whose forward saw
+        the older weights then raises instead of mixing them with activations of the newer ones."""
+        self._generation += 1
 
     def packed(self, stream):
         """Transposed / split weight copies used by the layer-wise GEMM path (pn_pack_weights).  Rebuilt on EVERY call:
@@ -140,8 +144,3 @@ class RadianceMLP(torch.nn.Module):
 
     def forward(self, *a, **kw):
         raise RuntimeError("RadianceMLP holds parameters only; call PanoMipNeRF / MipNeRF (pano_nerf_amd.render)")
-
-
-def mark_dirty(mlp):
-    """Kept for callers of round 1 (the packs are rebuilt on every forward now; nothing to invalidate)."""
-    mlp._version_packed = None

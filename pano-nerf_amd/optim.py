@@ -8,7 +8,6 @@ import math
 import torch
 
 from . import _lib
-from .mlp import mark_dirty
 
 
 def mip_lr(step, lr_init=2e-4, lr_final=2e-5, max_steps=44000, lr_delay_steps=120, lr_delay_mult=0.01):
@@ -40,7 +39,7 @@ class FlatAdam:
                       self.exp_avg_sq.data_ptr(), float(self.lr if lr is None else lr), float(self.betas[0]),
                       float(self.betas[1]), float(self.eps), int(self.step_count), float(grad_scale),
                       torch.cuda.current_stream(flat.device).cuda_stream)
-        mark_dirty(self.mlp)
+        self.mlp.note_raw_write()
 
     def step_dev(self, flat_grad, lr_dev, grad_scale=1.0):
         """Graph-replay friendly step: learning rate read from the 1-element device tensor `lr_dev`, step counter
@@ -56,7 +55,7 @@ class FlatAdam:
                       self.exp_avg_sq.data_ptr(), lr_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]),
                       float(self.eps), self.step_dev_t.data_ptr(), float(grad_scale),
                       torch.cuda.current_stream(flat.device).cuda_stream)
-        mark_dirty(self.mlp)
+        self.mlp.note_raw_write()
 
     def zero_grad(self):
         for p in self.mlp.parameters():

@@ -65,42 +65,60 @@ def rearrange_render_image(rays, chunk_size=4096):
 
 
 class DeviceRayPool:
-    """HBM-resident ray pool + batch sampler.
+    """Batch sampler over the pixels of a set of equirectangular cameras.
 
-    Stands in for the reference's flattened numpy pool and its 28 DataLoader workers
-    (datasets/pano_datasets.py:133-150, 271-275; systems/base_system.py:89-96): rays are generated on the device
-    from the camera matrices by ``pn_raygen_pano`` (nothing crosses PCIe per step) and a training batch is one
-    ``torch.randint`` + gather on the device.  ``images`` (optional) are the [H, W, 3] HDR targets per camera.
+    Stands in for the reference's flattened numpy ray pool and its 28 DataLoader workers
+    (datasets/pano_datasets.py:133-150, 271-275; systems/base_system.py:89-96).  NO ray pool is stored: a training
+    batch is one ``torch.randint`` over (camera, pixel) plus one kernel (``pn_sample_pano_rays``) that REGENERATES the
+    rays of the drawn pixels from the camera matrices with the arithmetic of ``pn_raygen_pano`` - bit-identical to a
+    gather out of the materialised pool (56 B/ray of HBM and of reads saved; nothing crosses PCIe per step).  Only the
+    target colours ``rgbs`` ([n_cam*H*W, 3], optional: ``images`` = [H, W, 3] HDR arrays per camera) are kept and gathered.
     """
 
     def __init__(self, height, width, c2ws, images=None, near=0.0, far=10.0, device="cuda"):
         self.h, self.w = int(height), int(width)
-        pools = [generate_pano_rays(height, width, c, near, far, device=device) for c in c2ws]
-        self.rays = Rays(*[torch.cat([getattr(p, k) for p in pools], 0) for k in Rays_keys])
-        self.radius = pano_pixel_radius(pools[0])
+        self.near, self.far = float(near), float(far)
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        mats = np.stack([np.asarray(c, dtype=np.float32).reshape(4, 4) for c in c2ws], 0)
+        self.c2ws_host = mats
+        self.c2ws = torch.from_numpy(np.ascontiguousarray(mats.reshape(len(mats), 16))).to(self.device)
+        self.n_cam = len(mats)
+        # the constant pixel radius of the pano (datasets/pano_datasets.py:215): the light rays carry it
+        self.radius = pano_pixel_radius(self.take(torch.zeros(1, dtype=torch.int64, device=self.device))[0])
         self.rgbs = None
         if images is not None:
-            self.rgbs = torch.cat([torch.as_tensor(im, dtype=torch.float32).reshape(-1, 3) for im in images], 0).to(
-                self.rays.origins.device)
+            self.rgbs = torch.cat([torch.as_tensor(im, dtype=torch.float32).reshape(-1, 3) for im in images], 0).to(self.device)
             if self.rgbs.shape[0] != len(self):
                 raise ValueError("images must be [H, W, 3] per camera")
 
     def __len__(self):
-        return self.rays.origins.shape[0]
+        return self.n_cam * self.h * self.w
+
+    @property
+    def rays(self):
+        """The materialised pool (camera-major, row-major pixels) - for tests and one-off uses; NOT cached."""
+        pools = [generate_pano_rays(self.h, self.w, c, self.near, self.far, device=self.device) for c in self.c2ws_host]
+        return Rays(*[torch.cat([getattr(p, k) for p in pools], 0) for k in Rays_keys])
+
+    def take(self, idx):
+        """Rays (and target colours) of the pool rows `idx` (int64 device tensor, row = camera * H * W + pixel)."""
+        dev = self.device
+        idx = idx.to(device=dev, dtype=torch.int64).contiguous()
+        B = int(idx.numel())
+        outs = [torch.empty(B, d, dtype=torch.float32, device=dev) for d in _DIMS]
+        rgbs = getattr(self, "rgbs", None)
+        rgb = torch.empty(B, 3, dtype=torch.float32, device=dev) if rgbs is not None else None
+        with torch.cuda.device(dev):
+            _lib.call("pn_sample_pano_rays", B, self.n_cam, self.h, self.w, idx.data_ptr(), self.c2ws.data_ptr(), self.near,
+                      self.far, _lib.ptr(rgbs), *[x.data_ptr() for x in outs], _lib.ptr(rgb), _stream(dev))
+        return Rays(*outs), rgb
 
     def sample(self, batch_size, generator=None):
         """-> (Rays of [B, C], rgb [B, 3] or None), all on the device."""
-        import ctypes
-        dev = self.rays.origins.device
-        B = int(batch_size)
-        idx = torch.randint(0, len(self), (B,), device=dev, generator=generator)
-        outs = [torch.empty(B, x.shape[1], dtype=torch.float32, device=dev) for x in self.rays]
-        rgb = torch.empty(B, 3, dtype=torch.float32, device=dev) if self.rgbs is not None else None
-        src = (ctypes.c_void_p * 9)(*[x.data_ptr() for x in self.rays], self.rgbs.data_ptr() if rgb is not None else None)
-        dst = (ctypes.c_void_p * 9)(*[x.data_ptr() for x in outs], rgb.data_ptr() if rgb is not None else None)
-        with torch.cuda.device(dev):
-            _lib.call("pn_gather_rays", B, len(self), idx.data_ptr(), src, dst, torch.cuda.current_stream(dev).cuda_stream)
-        return Rays(*outs), rgb
+        idx = torch.randint(0, len(self), (int(batch_size),), device=self.device, generator=generator)
+        return self.take(idx)
 
     def lit_rays(self, num=10, near=0.0, far=10.0):
-        return generate_lit_rays(num, self.radius, near, far, device=self.rays.origins.device)
+        return generate_lit_rays(num, self.radius, near, far, device=self.device)

@@ -36,18 +36,22 @@ for step in range(2):
     rays = pn.Rays(*[x[idx].to(dev) for x in flat])
     outs = ddp(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
     loss, _ = pn.pano_loss(outs, rays.lossmult, rgbs[idx].to(dev))
+    # the packed weights THIS forward read (the pack buffer is rebuilt in place by every forward) must be the pack of the
+    # weights as they stand now (the previous optimizer.step() included), and differ from the previous step's
+    st = torch.cuda.current_stream().cuda_stream
+    planes = pn.render._planes_of(model.mlp_mode)
+    used = model.mlp._chain[planes].clone()
+    fresh = torch.empty_like(used)
+    pn._lib.call("pn_chain_pack", model.mlp.flat.data_ptr(), 5, planes, fresh.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(used, fresh), "the forward ran on stale packed weights"
+    if step > 0:
+        assert not torch.equal(used, prev_used), "optimizer.step() did not reach the packed weights"
+    prev_used = used
     opt.zero_grad()
     loss.backward()
     opt.step()
     assert model.mlp.is_flat() and bool(torch.isfinite(model.mlp.flat).all())
-    # the packed weights the kernels read must follow the in-place optimizer step
-    st = torch.cuda.current_stream().cuda_stream
-    planes = pn.render._planes_of(model.mlp_mode)
-    used = model.mlp.chain_packed(st, planes).clone()
-    fresh = torch.empty_like(used)
-    pn._lib.call("pn_chain_pack", model.mlp.flat.data_ptr(), 5, planes, fresh.data_ptr(), st)
-    torch.cuda.synchronize()
-    assert torch.equal(used, fresh), "stale packed weights after optimizer.step()"
 # replicas stay identical: same averaged gradient, same update
 mine = model.mlp.flat.detach().cpu()
 both = [torch.empty_like(mine) for _ in range(world)]

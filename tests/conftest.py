@@ -39,7 +39,101 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / scale)
 
 
+def elementwise_rel_err(a, b, floor=1e-3):
+    """max over the elements with |b| > floor * max |b| of |a - b| / |b|: the element-wise relative error of the
+    north-star wording, taken where an element is not negligible against its tensor (a tensor-scale relative error,
+    `rel_err`, bounds it by rel_err / floor there)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    big = np.abs(b) > floor * max(float(np.max(np.abs(b))), 1e-30)
+    if not big.any():
+        return 0.0
+    return float(np.max(np.abs(a - b)[big] / np.abs(b)[big]))
+
+
+ELEMENTWISE_LOG = []  # (test id, tensor, tensor-scale error, element-wise error): printed at the end of the session
+
+
+def assert_close(got, ref, name, tol=1e-4, elementwise_tol=1e-4):
+    """Tensor-scale relative error <= tol AND, for the elements above 1e-3 of the tensor's max, element-wise relative
+    error <= elementwise_tol (well-conditioned outputs only: comp_rgb, distance, albedo, raw MLP outputs)."""
+    e, ee = rel_err(got, ref), elementwise_rel_err(got, ref)
+    ELEMENTWISE_LOG.append((name, e, ee))
+    assert e < tol, (name, "tensor-scale relative error", e)
+    assert ee < elementwise_tol, (name, "element-wise relative error where |ref| > 1e-3 max", ee, "tensor-scale", e)
+    return e, ee
+
+
+def pytest_terminal_summary(terminalreporter):
+    if ELEMENTWISE_LOG:
+        worst = {}
+        for name, e, ee in ELEMENTWISE_LOG:
+            k = name.split("/")[-1]
+            w = worst.get(k, (0.0, 0.0))
+            worst[k] = (max(w[0], e), max(w[1], ee))
+        terminalreporter.write_line("relative errors of the well-conditioned outputs (worst over this session): "
+                                    "tensor-scale | element-wise where |ref| > 1e-3 max")
+        for k, (e, ee) in sorted(worst.items()):
+            terminalreporter.write_line(f"  {k:12s} {e:.2e} | {ee:.2e}")
+
+
 FIRST_ORDER_TENSORS = ("extra_layer", "view_layers", "color_layer")
+
+
+def gates_of(ev, fused):
+    """[9, M, 256] boolean ReLU gates of one MLP evaluation, decoded from the bit words the kernels wrote (test hook:
+    `model.mlp.debug_keep = True` keeps the evaluation buffers of the last forward in `model.mlp.debug_pack`)."""
+    import torch
+    M = ev.M
+    words = ev.masks[:, :M].to(torch.int64) & 0xffffffff  # [9, M, 8]
+    f = torch.arange(256, device=words.device)
+    if fused:  # pn_chain.hip: lane group g = (f % QB) / 4 holds bit 4 (f / QB) + f % 4 of its 8 / NG words, QB = 4 NG, NG = 64 / tile
+        from pano_nerf_amd import _lib
+        tile = int(_lib.load().pn_chain_tile())
+        ng = 64 // tile
+        qb_size = 4 * ng
+        qb, g, i = f // qb_size, (f % qb_size) // 4, f % 4
+        bitpos = 4 * qb + i
+        w, bit = g * (8 // ng) + (bitpos >> 5), bitpos & 31
+    else:      # word col / 32, bit c * 8 + i for column 32 (col / 32) + 4 i + c (pn_common.h)
+        w, bit = f >> 5, (f & 3) * 8 + ((f & 31) >> 2)
+    return ((words[:, :, w] >> bit) & 1).bool().cpu()
+
+
+def forced_gate_sets(model, normals, surf):
+    """The gate decisions of the model's last forward in the order the oracle's mlp_forward calls consume them: level 0,
+    level 1, (level-1 normals), (env light)."""
+    pack = model.mlp.debug_pack
+    fused = model.mlp_mode != "layerwise"
+    g0, g1 = gates_of(pack[5], fused), gates_of(pack[6], fused)
+    sets = [g0, g1]
+    if normals:
+        sets.append(g1)
+    if surf:
+        sets.append(gates_of(pack[7], fused))
+    return sets
+
+
+def check_flat_grad_pointwise(flat_grad, ref_by_name, nc, tol=1e-4):
+    """EVERY entry of EVERY tensor of the flat gradient block within `tol` of the tensor's max |reference| — for references
+    computed on the SAME ReLU gate decisions (oracle.forced_gates).  Returns the worst tensor's error."""
+    from pano_nerf_amd.mlp import ORDER, param_layout
+    offs, total = param_layout(nc)
+    order = sorted(ORDER, key=lambda k: offs[k])
+    got_all = np.asarray(flat_grad, dtype=np.float64).reshape(-1)
+    assert got_all.size == total and np.isfinite(got_all).all()
+    worst = 0.0
+    for i, k in enumerate(order):
+        lo, hi = offs[k], offs[order[i + 1]] if i + 1 < len(order) else total
+        r = ref_by_name.get(k)
+        ref = np.zeros(hi - lo) if r is None else np.asarray(r, dtype=np.float64).reshape(-1)
+        if float(np.abs(ref).max()) == 0.0:
+            assert float(np.abs(got_all[lo:hi]).max()) <= 1e-12, (k, "expected a zero gradient")
+            continue
+        e = float(np.abs(got_all[lo:hi] - ref).max()) / float(np.abs(ref).max())
+        worst = max(worst, e)
+        assert e <= tol, (k, "max |err| / max |ref| on identical gates", e)
+    return worst
 
 
 def check_flat_grad_per_tensor(flat_grad, ref_by_name, nc, second_order, n_rows=0):
@@ -49,7 +143,8 @@ def check_flat_grad_per_tensor(flat_grad, ref_by_name, nc, second_order, n_rows=
     flips (pre-activation ~1e-7, any fp32 summation order) make the gradient discontinuous — the reference's fp32 run
     differs from its own fp64 run by up to 2.8e-3 of the tensor max there: median <= 2e-4, relative L2 <= 2e-2, and for
     weight matrices every entry within 2e-4 once the low-rank part of the error that a handful of flipped gates explain
-    (rank 4 + n_rows / 500) is removed (tests/test_gpu_grads.py has the rationale and the pointwise, gate-consistent form)."""
+    (rank 4 + n_rows / 500, never more than 8) is removed (tests/test_gpu_grads.py has the rationale; the pointwise,
+    gate-consistent form is check_flat_grad_pointwise)."""
     from pano_nerf_amd.mlp import ORDER, param_layout
     offs, total = param_layout(nc)
     order = sorted(ORDER, key=lambda k: offs[k])
@@ -72,11 +167,13 @@ def check_flat_grad_per_tensor(flat_grad, ref_by_name, nc, second_order, n_rows=
             rl2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
             assert rl2 <= 2e-2, (k, "relative L2", rl2)
             shape = _weight_shape(k, nc)
-            if shape is not None and min(shape) > 8:
+            r = 4 + n_rows // 500
+            if shape is not None and min(shape) > 8 and r <= 8:
                 # every entry within 2e-4 beyond what a handful of flipped gates explain: 4, plus one per 500 MLP sample
                 # rows of the step (the expected number of flips grows with rows x 2304 gates; each flip adds a
-                # rank-one term per path, first- and second-order)
-                r = min(4 + n_rows // 500, min(shape) // 4)
+                # rank-one term per path, first- and second-order).  Only while that handful is <= 8: with more rows a
+                # larger rank would hide real kernel errors, and the callers compare pointwise against the oracle run on
+                # the kernels' own gate decisions instead (check_flat_grad_pointwise)
                 e2 = ((got - ref) / scale).reshape(shape)
                 u, sv, vt = np.linalg.svd(e2, full_matrices=False)
                 resid = np.abs(e2 - (u[:, :r] * sv[:r]) @ vt[:r])

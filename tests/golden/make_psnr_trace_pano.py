@@ -26,7 +26,21 @@ def schedule(seed=11):
         yield idx, t_rand, u_rand, env_rand
 
 
-def train(dtype):
+def perturbed_init(seed):
+    """The initial weights with EVERY element moved by one ulp up or down (sign from PCG64(seed)); seed None: unchanged."""
+    params = orc.init_params(4, 5)
+    if seed is None:
+        return params
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k, v in params.items():
+        up = torch.from_numpy(rng.integers(0, 2, size=tuple(v.shape)).astype(np.bool_))
+        inf = torch.full_like(v, float("inf"))
+        out[k] = torch.where(up, torch.nextafter(v, inf), torch.nextafter(v, -inf))
+    return out
+
+
+def train(dtype, perturb_seed=None):
     torch.set_default_dtype(dtype)
     try:
         flat, rgbs, radius, _ = orc.synthetic_scene(H, W, 3, seed=4)
@@ -36,7 +50,7 @@ def train(dtype):
         envf = Rays(*[x.float().to(dtype) for x in env])
         net = rpano.PanoMipNeRF(num_samples=N, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5,
                                 num_env_samples=10).to(dtype)
-        mg.load_params(net.mlp, {k: v.to(dtype) for k, v in orc.init_params(4, 5).items()})
+        mg.load_params(net.mlp, {k: v.to(dtype) for k, v in perturbed_init(perturb_seed).items()})
         opt = torch.optim.Adam(net.mlp.parameters(), lr=2e-4)
         sch = MipLRDecay(opt, 2e-4, 2e-5, 44000, 120, 0.01)
         losses = []

@@ -167,3 +167,81 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc, pla
         worst = max(worst, e)
         assert e < 1e-4, (k, e)
     print(f"chain kernels vs fp64 autograd (M={M}, nc={nc}): worst gradient tensor error {worst:.2e}")
+
+
+@pytest.mark.parametrize("order", ["big_first", "small_first"])
+def test_weight_gradients_over_segments_whose_magnitudes_are_1e30_apart(order):
+    """pn_chain_wgrad (fp16 pairs) over TWO evaluations whose delta tensors differ by a factor 1e30: every GEMM of the job
+    uses ONE unit (the dominant segment's), so a workgroup whose sample range crosses from one evaluation into the other
+    never re-bases its sums (re-basing by 2^+-100 overflowed or flushed them).  Synthetic T tensors, fp64 reference."""
+    from pano_nerf_amd import _lib
+    from pano_nerf_amd.mlp import ORDER, param_layout
+    lib = _lib.load()
+    tile = int(lib.pn_chain_tile())
+    nc, M = 5, 1024
+    Mp = int(lib.pn_pad_rows(M))
+    assert Mp == M
+    offs, total = param_layout(nc)
+    gen = torch.Generator().manual_seed(5)
+    scales = (1e15, 1e-15) if order == "big_first" else (1e-15, 1e15)
+    AM = dict(enc=0, act=1, delta=11, d8b=19, d8d=20, dhv=21, drgb=22)
+
+    def t_of(rows):  # [Mp, F] rows -> T layout [Mp / tile][F][tile]
+        F = rows.shape[1]
+        return rows.reshape(Mp // tile, tile, F).permute(0, 2, 1).contiguous().reshape(-1)
+
+    evs, keep, want, shapes = [], [], {}, {}
+    for k in ORDER:
+        nxt = min([o for o in offs.values() if o > offs[k]] + [total])
+        shapes[k] = nxt - offs[k]
+        want[k] = np.zeros(shapes[k], np.float64)
+    for sc in scales:
+        R = lambda f, s=1.0: torch.randn(Mp, f, generator=gen) * s
+        enc = R(96).clamp(-1, 1)
+        acts = [torch.relu(R(256)) for _ in range(8)] + [R(288), torch.relu(R(128))]
+        delta = [R(256, sc) * (torch.rand(Mp, 256, generator=gen) > 0.5) for _ in range(8)]
+        d8 = torch.cat([R(256, sc), R(nc, sc), torch.zeros(Mp, 32 - nc)], 1)
+        dhv, drgb = R(128, sc), torch.cat([R(3, sc), torch.zeros(Mp, 29)], 1)
+        amax = torch.zeros(int(lib.pn_chain_amax_slots()), dtype=torch.float32)
+        amax[AM["enc"]] = enc.abs().max()
+        for i, a in enumerate(acts):
+            amax[AM["act"] + i] = a.abs().max()
+        for i, d in enumerate(delta):
+            amax[AM["delta"] + i] = d.abs().max()
+        amax[AM["d8b"]], amax[AM["d8d"]] = d8[:, :256].abs().max(), d8[:, 256:].abs().max()
+        amax[AM["dhv"]], amax[AM["drgb"]] = dhv.abs().max(), drgb.abs().max()
+        dv = lambda t: t.to(dev())
+        bufs = dict(enc_t=dv(t_of(enc)),
+                    acts_t=dv(torch.cat([t_of(a) for a in acts])),
+                    drgb_t=dv(t_of(drgb)), dhv_t=dv(t_of(dhv)), d8_t=dv(t_of(d8)),
+                    delta_t=dv(torch.cat([t_of(d) for d in delta])), amax=dv(amax.view(torch.int32)))
+        keep.append(bufs)
+        evs.append(EvalC(M, bufs["enc_t"].data_ptr(), bufs["acts_t"].data_ptr(), bufs["drgb_t"].data_ptr(), bufs["dhv_t"].data_ptr(),
+                         bufs["d8_t"].data_ptr(), bufs["delta_t"].data_ptr(), None, None, None, None, bufs["amax"].data_ptr()))
+        D = lambda t: t.double().numpy()
+        for l in range(8):
+            y = enc if l == 0 else (torch.cat([acts[4], enc], 1) if l == 5 else acts[l - 1])
+            want[f"layers.{l}.0.weight"] += (D(delta[l]).T @ D(y)).reshape(-1)
+            want[f"layers.{l}.0.bias"] += D(delta[l]).sum(0)
+        want["extra_layer.weight"] += (D(d8[:, :256]).T @ D(acts[7])).reshape(-1)
+        want["extra_layer.bias"] += D(d8[:, :256]).sum(0)
+        want["density_layer.weight"] += (D(d8[:, 256:256 + nc]).T @ D(acts[7])).reshape(-1)
+        want["density_layer.bias"] += D(d8[:, 256:256 + nc]).sum(0)
+        want["view_layers.0.0.weight"] += (D(dhv).T @ D(acts[8][:, :283])).reshape(-1)
+        want["view_layers.0.0.bias"] += D(dhv).sum(0)
+        want["color_layer.weight"] += (D(drgb[:, :3]).T @ D(acts[9])).reshape(-1)
+        want["color_layer.bias"] += D(drgb[:, :3]).sum(0)
+    arr = (EvalC * 2)(*evs)
+    grads = torch.zeros(total, dtype=torch.float32, device=dev())
+    wfl = int(lib.pn_chain_wgrad_work_floats())
+    work = torch.empty(wfl, dtype=torch.float32, device=dev())
+    lib.pn_chain_wgrad.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int64, ctypes.c_void_p]
+    _lib.check(lib.pn_chain_wgrad(2, ctypes.cast(arr, ctypes.c_void_p), nc, 2, grads.data_ptr(), work.data_ptr(), wfl, st()),
+               "pn_chain_wgrad")
+    torch.cuda.synchronize()
+    got = grads.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    for k in ORDER:
+        e = rel(got[offs[k]:offs[k] + shapes[k]], want[k])
+        assert e < 1e-5, (k, e)

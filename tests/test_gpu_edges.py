@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_flat_grad_per_tensor, rel_err
+from conftest import check_flat_grad_per_tensor, check_flat_grad_pointwise, forced_gate_sets, rel_err
 from oracle import pano_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -30,11 +30,13 @@ def test_ragged_and_tiny_batches_match_oracle(B, N):
     model = pn.PanoMipNeRF(num_samples=N, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5)
     model.mlp.load_state_dict(params)
     model = model.to(dev())
+    model.mlp.debug_keep = True
     outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
     loss, _ = pn.pano_loss(outs, rays.lossmult, rgbs.to(dev()))
     loss.backward()
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    ref = orc.pano_forward(p, rays_c, orc.Rays(*[x.cpu() for x in env]), num_samples=N)
+    env_c = orc.Rays(*[x.cpu() for x in env])
+    ref = orc.pano_forward(p, rays_c, env_c, num_samples=N)
     ref_loss = orc.pano_loss(ref, rays_c.lossmult, rgbs)
     for lvl in (0, 1):
         assert rel_err(outs[lvl][0].detach().cpu(), ref[lvl][0].detach()) < 1e-4
@@ -46,6 +48,11 @@ def test_ragged_and_tiny_batches_match_oracle(B, N):
     ref_g = torch.autograd.grad(ref_loss, list(p.values()))
     check_flat_grad_per_tensor(g.detach().cpu().numpy(), {k: x.detach().numpy() for k, x in zip(p.keys(), ref_g)}, 5,
                                second_order=True, n_rows=B * (2 * N + 100))
+    # pointwise, every entry of every tensor: the oracle on the gate decisions the kernels took
+    with orc.forced_gates(forced_gate_sets(model, normals=True, surf=True)):
+        fl = orc.pano_loss(orc.pano_forward(p, rays_c, env_c, num_samples=N), rays_c.lossmult, rgbs)
+        fg = torch.autograd.grad(fl, list(p.values()))
+    check_flat_grad_pointwise(g.detach().cpu().numpy(), {k: x.detach().numpy() for k, x in zip(p.keys(), fg)}, 5)
 
 
 def test_maximum_sample_count():
@@ -140,6 +147,7 @@ def test_assorted_configurations_match_oracle(cfg):
         ref_loss = orc.mip_loss(ref, rays_c.lossmult, rgbs, use_ort=ort)
     model.mlp.load_state_dict(params)
     model = model.to(dev())
+    model.mlp.debug_keep = True
     if rnd:
         model.noise_override = noise
     outs = model(**kw)
@@ -161,6 +169,19 @@ def test_assorted_configurations_match_oracle(cfg):
                                {k: (None if x is None else x.detach().numpy()) for k, x in zip(p.keys(), ref_g)},
                                5 if kind == "pano" else 1, second_order=bool(ort) or kind == "pano",
                                n_rows=B * (2 * N + (100 if (kind == "pano" and surf) else 0)))
+    # pointwise, every entry of every tensor: the oracle on the gate decisions the kernels took (these cases run up to
+    # 42 k MLP rows, where a rank-stripped comparison would hide errors of rank up to 64)
+    with orc.forced_gates(forced_gate_sets(model, normals=(kind == "pano" or bool(ort)), surf=(kind == "pano" and bool(surf)))):
+        if kind == "pano":
+            fl = orc.pano_loss(orc.pano_forward(p, rays_c, orc.Rays(*[x.cpu() for x in env]), num_samples=N, white_bkgd=white,
+                                                enable_surf=surf, use_ort_loss=ort, noise=noise), rays_c.lossmult, rgbs, surface=surf)
+        else:
+            fl = orc.mip_loss(orc.mip_forward(p, rays_c, num_samples=N, white_bkgd=white, use_ort_loss=ort, noise=noise),
+                              rays_c.lossmult, rgbs, use_ort=ort)
+        fg = torch.autograd.grad(fl, list(p.values()), allow_unused=True)
+    check_flat_grad_pointwise(g.detach().cpu().numpy(),
+                              {k: (None if x is None else x.detach().numpy()) for k, x in zip(p.keys(), fg)},
+                              5 if kind == "pano" else 1)
 
 
 @pytest.mark.parametrize("mode", ["fused_f16x2", "fused"])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close, rel_err
 from oracle import pano_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -74,7 +74,7 @@ def check_tuple(outs, g, prefix, names, g64=None):
                     drop = max(3, int(np.ceil(0.05 * got.shape[0])))  # rays allowed to sit on a flipped gate
                     assert ours[-drop - 1] <= 2 * theirs[-drop - 1] + 1e-5, (key, ours[-3:], theirs[-3:])
             else:
-                assert e < 1e-4, (key, e)
+                assert_close(got, g[key], key)  # tensor-scale 1e-4 and element-wise 1e-4 where |ref| > 1e-3 max
 
 
 def check_grads(model, g, prefix):
@@ -247,6 +247,81 @@ def test_bench_size_properties():
         l2.backward()
         halves.append(model.mlp.last_flat_grad.clone())
         model.noise_override = ov
+    avg = 0.5 * (halves[0] + halves[1])
+    assert float((avg - full).norm() / full.norm()) < 1e-4
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_headline_size_matches_oracle_on_a_ray_subset(mode):
+    """The BASELINE / bench.py size - 4096 rays x 128 + 128 samples (M = 524 288 rows per level, 16 tiles per persistent
+    workgroup, 409 600 env-light rows), train mode with fixed noise - checked against the oracle: rays are independent, so
+    the oracle run on a strided 32-ray subset (with those rays' noise rows) must reproduce the subset of every per-ray
+    output of the 4096-ray call.  Plus the size-independent properties of test_bench_size_properties.
+    Reference: models/pano_mip_nerf.py:197-363."""
+    import pano_nerf_amd as pn
+    B, N, K = 4096, 128, 32
+    S = N + 1
+    flat, rgbs, radius, _ = orc.synthetic_scene(64, 128, 3, seed=4)
+    idx = torch.randint(0, flat.origins.shape[0], (B,), generator=torch.Generator().manual_seed(4096))
+    rays_c = orc.Rays(*[x[idx] for x in flat])
+    rays = to_dev(pn.Rays(*rays_c))
+    gt = rgbs[idx].to(dev())
+    env = pn.generate_lit_rays(10, radius)
+    env_c = orc.Rays(*[x.cpu() for x in env])
+    model = make_pano(N)
+    model.mlp_mode = mode
+    gen = torch.Generator().manual_seed(7)
+    noise = dict(t_rand=torch.rand(B, S, generator=gen), u_rand=torch.rand(B, S, generator=gen) * (1.0 / S - 1.2e-7),
+                 env_rand=torch.rand(1, 11, generator=gen))
+    model.noise_override = noise
+    outs = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    loss, _ = pn.pano_loss(outs, rays.lossmult, gt)
+    loss.backward()
+    grad = model.mlp.last_flat_grad
+    assert bool(torch.isfinite(loss)) and bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0
+    # ---- the oracle on every 128th ray
+    sub = torch.arange(0, B, B // K)
+    sub_rays = orc.Rays(*[x[sub] for x in rays_c])
+    sub_noise = dict(t_rand=noise["t_rand"][sub], u_rand=noise["u_rand"][sub], env_rand=noise["env_rand"])
+    p = orc.init_params(4, 5)
+    with torch.no_grad():
+        ref = orc.pano_forward(p, sub_rays, env_c, num_samples=N, noise=sub_noise)
+    flips = 0
+    for lvl in (0, 1):
+        for nme, v, r in zip(NAMES9, outs[lvl], ref[lvl]):
+            assert (v is None) == (r is None), (lvl, nme)
+            if v is None or nme == "ort_loss":  # (a mean over all 4096 rays: not a per-ray output)
+                continue
+            got, want = v.detach()[sub.to(dev())].cpu().numpy(), r.numpy()
+            key = f"headline/{mode}/l{lvl}/{nme}"
+            if nme in LOOSE:
+                # derived from the density gradient: a ReLU gate with a pre-activation of ~1e-7 flips under any fp32 summation
+                # order and moves ONE ray; median at 1e-4 and at most two of the 32 rays beyond 1e-3 (SURVEY.md 7)
+                scale = max(float(np.abs(want).max()), 1e-12)
+                per_ray = np.abs(got - want).reshape(K, -1).max(-1) / scale
+                assert float(np.median(per_ray)) < 1e-4, (key, float(np.median(per_ray)))
+                assert int((per_ray > 1e-3).sum()) <= 2, (key, per_ray)
+                flips = max(flips, int((per_ray > 1e-3).sum()))
+            else:
+                assert_close(got, want, key)
+    # ---- size-independent properties at this size
+    (c0, d0, *_), (c1, d1, ort, nrm, alb, _, sf, dif, shd) = outs
+    assert torch.allclose(nrm.norm(dim=-1), torch.ones(B, device=dev()), atol=1e-4)
+    assert float(alb.min()) >= 0.03 - 1e-6 and float(alb.max()) <= 0.80 + 1e-6
+    assert bool((d1 >= 0).all()) and bool((d1 <= 10).all()) and bool((d0 >= 0).all()) and bool((d0 <= 10).all())
+    assert torch.equal(sf, dif) and bool(torch.isfinite(shd).all()) and float(ort) >= 0
+    outs_b = model(rays=rays, env_rays=env, randomized=True, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    assert torch.equal(outs_b[1][0], c1) and torch.equal(outs_b[1][6], sf)  # determinism: same inputs, same bits
+    # shard additivity at the 2-GPU share: the mean-loss gradient = the average of the two 2048-ray gradients
+    full = grad.clone()
+    halves = []
+    for lo, hi in ((0, B // 2), (B // 2, B)):
+        model.noise_override = dict(t_rand=noise["t_rand"][lo:hi], u_rand=noise["u_rand"][lo:hi], env_rand=noise["env_rand"])
+        o2 = model(rays=pn.Rays(*[x[lo:hi] for x in rays]), env_rays=env, randomized=True, white_bkgd=False, enable_surf=True,
+                   use_ort_loss=True)
+        l2, _ = pn.pano_loss(o2, rays.lossmult[lo:hi], gt[lo:hi])
+        l2.backward()
+        halves.append(model.mlp.last_flat_grad.clone())
     avg = 0.5 * (halves[0] + halves[1])
     assert float((avg - full).norm() / full.norm()) < 1e-4
 

@@ -186,22 +186,7 @@ def test_plain_bf16_mode_against_the_autocast_reference(golden, case):
 
 
 # ---------------------------------------------------------------------------- gate-consistent pointwise parity
-def gates_of(ev, fused):
-    """[9, M, 256] boolean ReLU gates of one evaluation, decoded from the bit words the kernels wrote."""
-    M = ev.M
-    words = ev.masks[:, :M].to(torch.int64) & 0xffffffff  # [9, M, 8]
-    f = torch.arange(256, device=words.device)
-    if fused:  # pn_chain.hip: lane group g = (f % QB) / 4 holds bit 4 (f / QB) + f % 4 of its 8 / NG words, QB = 4 NG, NG = 64 / tile
-        from pano_nerf_amd import _lib
-        tile = int(_lib.load().pn_chain_tile())
-        ng = 64 // tile
-        qb_size = 4 * ng
-        qb, g, i = f // qb_size, (f % qb_size) // 4, f % 4
-        bitpos = 4 * qb + i
-        w, bit = g * (8 // ng) + (bitpos >> 5), bitpos & 31
-    else:      # word col / 32, bit c * 8 + i for column 32 (col / 32) + 4 i + c (pn_common.h)
-        w, bit = f >> 5, (f & 3) * 8 + ((f & 31) >> 2)
-    return ((words[:, :, w] >> bit) & 1).bool().cpu()
+from conftest import gates_of  # noqa: E402  (shared with tests/test_gpu_edges.py, tests/test_gpu_full.py)
 
 
 @pytest.mark.parametrize("mode", MODES)

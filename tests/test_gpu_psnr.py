@@ -70,9 +70,11 @@ def schedule_pano(steps, B, N, H, W, seed=11):
 def test_pano_training_matches_reference_trace(golden, mode):
     """The north-star PSNR target is for the panonerf step: surface + chromaticity + orientation terms, second-order
     gradients (systems/panonerf_system.py:15-75).  Same weights, batches and all three noise draws as the imported
-    reference was trained with on CPU (tests/golden/make_psnr_trace_pano.py).  Gates: the loss curve stays as close to the
-    reference's as the reference's own fp64 run does (x3; 2e-3 where that is tighter), and the held-out-view PSNR
-    (volume and surface) lies within 0.1 dB of the band spanned by the reference's fp32 and fp64 runs (see below)."""
+    reference was trained with on CPU (tests/golden/make_psnr_trace_pano.py).  This 64-ray run is chaotic (ReLU-gate flips
+    through the second-order path), so the yardstick is a DISTRIBUTION of the reference's own fp32 trajectories: the
+    fixture's run plus six runs whose initial weights differ by one ulp per element (tests/golden/make_psnr_ensemble_pano.py).
+    Gates: the held-out-view PSNR - volume and surface, each on ITS OWN spread - lies within 0.1 dB of the reference's own
+    min..max; the loss curve stays as close to the fixture's as the reference's own perturbed runs do (x1.5)."""
     import pano_nerf_amd as pn
     g = golden("psnr_trace_pano")
     steps, B, N, H, W = (int(g[k]) for k in ("steps", "B", "N", "H", "W"))
@@ -102,18 +104,19 @@ def test_pano_training_matches_reference_trace(golden, mode):
     losses = np.array(losses)
     ref = g["losses"]
     rel = np.abs(losses - ref) / ref
-    # yardstick: the reference against ITSELF in fp64 (same weights, batches, noise): ReLU-gate flips through the
-    # second-order path make this 64-ray training trajectory chaotic — its fp32 and fp64 loss curves part by 1.7e-3 within
-    # 5 steps, 1.1e-2 within 20 and its surface PSNR by 0.11 dB (tests/golden/make_psnr_trace_pano.py)
-    own = np.abs(g["losses"] - g["losses64"]) / g["losses64"]
+    # yardstick: the reference against ITSELF - six fp32 runs from initial weights one ulp away (and its fp64 run, printed)
+    ens = golden("psnr_ensemble_pano")
+    dev_runs = np.abs(ens["losses"] - ref[None]) / ref[None]  # [runs, steps]
+    own = np.array([dev_runs[:, :5].max(), dev_runs[:, :20].max(), np.median(dev_runs, axis=1).max(), dev_runs.max()])
+    own64 = np.abs(g["losses"] - g["losses64"]) / g["losses64"]
     print(f"pano trace {mode}: rel loss error steps 0-4 {rel[:5].max():.2e}, 0-19 {rel[:20].max():.2e}, median {np.median(rel):.2e}, "
-          f"max {rel.max():.2e}   (reference fp32 vs fp64: {own[:5].max():.2e}, {own[:20].max():.2e}, {np.median(own):.2e}, "
-          f"{own.max():.2e})")
-    # (x3: how far a chaotic trajectory has moved after k steps is itself random; the PSNR band below is the criterion)
-    assert rel[:5].max() < max(2e-3, 3 * own[:5].max()), rel[:5].max()
-    assert rel[:20].max() < max(2e-3, 3 * own[:20].max()), rel[:20].max()
-    assert np.median(rel) < max(2e-3, 3 * np.median(own)), np.median(rel)
-    assert rel.max() < max(2e-2, 3 * own.max()), rel.max()
+          f"max {rel.max():.2e}   (reference's own 1-ulp-perturbed fp32 runs, worst of 6: {own[0]:.2e}, {own[1]:.2e}, {own[2]:.2e}, "
+          f"{own[3]:.2e}; its fp64 run: {own64[:5].max():.2e}, {own64[:20].max():.2e}, {np.median(own64):.2e}, {own64.max():.2e})")
+    # (x1.5: how far a chaotic trajectory has moved after k steps is itself random; the PSNR band below is the criterion)
+    assert rel[:5].max() < max(2e-3, 1.5 * own[0]), rel[:5].max()
+    assert rel[:20].max() < 1.5 * own[1], rel[:20].max()
+    assert np.median(rel) < 1.5 * own[2], np.median(rel)
+    assert rel.max() < 1.5 * own[3], rel.max()
     hold = torch.arange(2 * H * W, 3 * H * W, 16, device=dev)
     model.noise_override = None
     with torch.no_grad():
@@ -123,18 +126,12 @@ def test_pano_training_matches_reference_trace(golden, mode):
     psnr_s = pn.loss.hdr_to_ldr_psnr(outs[1][6], rgbs_d[hold])
     print(f"pano trace {mode}: PSNR {psnr:.3f} (reference fp32 {float(g['psnr']):.3f}, fp64 {float(g['psnr64']):.3f}), surface PSNR "
           f"{psnr_s:.3f} ({float(g['psnr_surface']):.3f}, {float(g['psnr_surface64']):.3f})")
-    # Within 0.1 dB of the reference, whose own fp32 and fp64 runs bracket the admissible band.  How far the chaotic
-    # trajectory moves a held-out PSNR is what those two runs show: 0.113 dB on the surface PSNR, by chance 0.007 dB on the
-    # volume PSNR of the same trajectories.  Each metric's band is therefore at least as wide as the larger of the two
-    # (all four kernel modes land 0.01 - 0.10 dB from the reference's volume PSNR, the exact-fp32 layer-wise path included).
-    spread = max(abs(float(g["psnr"]) - float(g["psnr64"])), abs(float(g["psnr_surface"]) - float(g["psnr_surface64"])))
-
-    def band(a, b):
-        lo, hi = sorted((float(a), float(b)))
-        pad = max(0.0, spread - (hi - lo)) / 2
-        return lo - pad - 0.1, hi + pad + 0.1
-
-    lo, hi = band(g["psnr"], g["psnr64"])
-    assert lo <= psnr <= hi, (psnr, lo, hi)
-    lo, hi = band(g["psnr_surface"], g["psnr_surface64"])
-    assert lo <= psnr_s <= hi, (psnr_s, lo, hi)
+    # Within 0.1 dB of the reference's own fp32 distribution (7 runs: the fixture's + 6 one-ulp-perturbed), each metric on
+    # its own min..max: volume 24.630 .. 24.699 dB, surface 23.834 .. 23.992 dB (the fp64 run, 24.645 / 23.879, lies inside)
+    vol = np.concatenate([[float(g["psnr"])], ens["psnr"]])
+    srf = np.concatenate([[float(g["psnr_surface"])], ens["psnr_surface"]])
+    assert len(vol) >= 6
+    print(f"pano trace {mode}: reference fp32 distribution: volume {vol.min():.3f} .. {vol.max():.3f}, surface {srf.min():.3f} .. "
+          f"{srf.max():.3f} dB")
+    assert vol.min() - 0.1 <= psnr <= vol.max() + 0.1, (psnr, vol.min(), vol.max())
+    assert srf.min() - 0.1 <= psnr_s <= srf.max() + 0.1, (psnr_s, srf.min(), srf.max())

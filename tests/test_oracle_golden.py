@@ -187,6 +187,16 @@ def test_lr_schedule(golden):
         assert abs(orc.mip_lr(int(step)) - float(lr)) < 1e-12 + 1e-9 * float(lr)
 
 
+def test_package_lr_schedule_matches_the_reference(golden):
+    """pano_nerf_amd.optim.mip_lr (the product's copy, used by bench.py and the training tests) against the values the
+    reference's MipLRDecay produced (utils/lr_schedule.py:51-59; tests/golden/make_golden.py)."""
+    from pano_nerf_amd.optim import mip_lr
+    g = golden("lr_schedule")
+    assert len(g["steps"]) >= 4
+    for step, lr in zip(g["steps"], g["lrs"]):
+        assert abs(mip_lr(int(step)) - float(lr)) < 1e-12 + 1e-9 * float(lr), (int(step), mip_lr(int(step)), float(lr))
+
+
 @pytest.mark.parametrize("case", ["B64_N32", "B16_N128"])
 def test_oracle_full_gradients_match_the_reference(golden, case):
     """Every entry of d loss / d params (614 k values) of the oracle against the imported reference's fp32 gradients

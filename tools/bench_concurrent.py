@@ -51,14 +51,12 @@ def bench(fn, name, graph):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     if graph:
-        from pano_nerf_amd.mlp import mark_dirty
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             fn(); fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        mark_dirty(model.mlp)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fn()
