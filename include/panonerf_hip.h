@@ -203,9 +203,11 @@ int64_t pn_chain_acts_floats(int64_t M);
  * every T tensor the weight gradients will read (float bits).  pn_chain_forward clears it, the four chain kernels of the
  * evaluation add their tensors' maxima, pn_chain_wgrad derives one power-of-two scale per tensor from it. */
 int pn_chain_amax_slots(void);
+/* view_tab: scratch of view_rows * 32 floats - the view encoding (pos_enc, models/mip.py:431-441) depends on the view row
+ * only, so it is evaluated once per row (a small kernel in front of the chain) and read by the row's samples. */
 int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, int planes,
-                     const void* pack, const float* mean, const float* cov, const float* viewdirs, float* enc_t,
-                     float* acts_t, uint32_t* masks, float* raw_rgb /*[M,3]*/, float* raw_density /*[M,nc]*/,
+                     const void* pack, const float* mean, const float* cov, const float* viewdirs, float* view_tab,
+                     float* enc_t, float* acts_t, uint32_t* masks, float* raw_rgb /*[M,3]*/, float* raw_density /*[M,nc]*/,
                      uint32_t* amax, void* stream);
 /* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep.  keep_all != 0: rs_t is
  * T [8][Mp*256] and receives r_0..r_7 (the second-order weight gradients need them); keep_all = 0 (inference): rs_t is ONE

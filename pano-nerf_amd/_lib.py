@@ -52,7 +52,7 @@ SIGNATURES = {
     "pn_chain_pack": ("i", "piipp"),
     "pn_chain_acts_floats": ("l", "l"),
     "pn_chain_amax_slots": ("i", ""),
-    "pn_chain_forward": ("i", "lilii" + "p" * 10 + "p"),
+    "pn_chain_forward": ("i", "lilii" + "p" * 11 + "p"),
     "pn_chain_density_grad": ("i", "liif" + "p" * 7 + "ippp"),
     "pn_chain_tangent": ("i", "lii" + "p" * 10 + "p"),
     "pn_chain_backward": ("i", "liif" + "p" * 15 + "p"),

@@ -81,10 +81,18 @@ constexpr int KS_C = 128 / KSTEP, NT_C = 128 / TILE;      // the 128-wide view h
 template <int NP>
 struct Cfg {
     // fragments (1 KB each) per chunk; with two workgroups per CU a ring of three slots must stay under 80 KB
+#ifdef PN_CHAIN_CF  // (experiments: chunk size in fragments)
+    static constexpr int CF = PN_CHAIN_CF;
+#else
     static constexpr int CF = NP >= 2 ? 24 : (CH_WG_PER_CU == 2 ? 16 : 32);
+#endif
     static constexpr int PER = CF / NP;                // GEMM steps (one A fragment set each) per chunk
     static constexpr int SLOT = (CF + 1) * 1024;       // + 1 KB of aux floats (bias) per chunk
+#ifdef PN_CHAIN_NSLOT
+    static constexpr int NSLOT = PN_CHAIN_NSLOT;
+#else
     static constexpr int NSLOT = CH_WG_PER_CU == 2 ? 3 : (NP >= 2 ? 5 : 4);  // ring slots
+#endif
     static constexpr int D = NSLOT - 1;                // chunks in flight ahead of the one being consumed
     static constexpr int SHARE = CF / CH_WAVES;        // DMA instructions EVERY wave issues per chunk (waves 0-3 one more)
     static constexpr int LDS_BYTES = SLOT * NSLOT;
@@ -167,7 +175,7 @@ struct PackLayer {
     int rows_valid;
     int nseg;
     PackSeg seg[2];
-    int64_t aux_off;  // floats copied to the aux KB of the layer's first chunk (bias); < 0: zeros
+    int64_t aux_off;  // floats copied to the aux KB of the layer's LAST chunk (bias, added when the sum is complete); < 0: zeros
     int aux_n;
 };
 #define PACK_MAXL 16
@@ -240,7 +248,7 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
     unsigned char* dst = out + (int64_t)chunk * SLOT + f * 1024 + lane * 16;
     if (f == CF) {  // aux: 256 floats, 4 per lane
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (chunk == L.chunk0 && L.aux_off >= 0)
+        if (chunk == L.chunk0 + (L.KS * L.NT + PER - 1) / PER - 1 && L.aux_off >= 0)  // the GEMM's LAST chunk
             for (int q = 0; q < 4; ++q)
                 if (lane * 4 + q < L.aux_n) v[q] = params[L.aux_off + lane * 4 + q];
         memcpy(dst, v, 16);
@@ -401,6 +409,14 @@ struct Ring {
     }
 };
 
+// Eight waves in one workgroup: the second-dispatched half (waves 4-7) loses every issue arbitration against its SIMD
+// partner at equal priority (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority step for that half.
+__device__ __forceinline__ void chain_prio(int wid) {
+#ifdef PN_CHAIN_PRIO
+    if (wid >= CH_WAVES / 2) __builtin_amdgcn_s_setprio(PN_CHAIN_PRIO);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------ the GEMM
 __device__ __forceinline__ accv mfma1(const bf16x8& a, const bf16x8& b, accv v) {
 #if PN_CHAIN_TILE == 32
@@ -489,7 +505,9 @@ template <int NP, int S, int PP, bool BIASNEXT>
 __device__ __forceinline__ void piece_step(Ring<NP>& R) {
     if constexpr (PP < S && !(PN_ABL_CHAIN & 1)) {
         constexpr int PER = Cfg<NP>::PER, c = PP / PER, n = (S + PER - 1) / PER;
-        R.template pieces_from<PP % PER, chunk_steps<NP>(S, c), (BIASNEXT && c + Cfg<NP>::D >= n)>();
+        // (every round carries the aux KB: which rounds reach a chunk with a bias is static, but leaving the others out
+        // bought nothing measurable - 14 % fewer DMA instructions, same time)
+        R.template pieces_from<PP % PER, chunk_steps<NP>(S, c), true>();
     }
 }
 template <int NP>
@@ -566,33 +584,21 @@ __device__ __forceinline__ void gemm_prologue(Ring<NP>& R, uint32_t sa, BFrag<NP
         gemm_prologue<NP, S, I + 1, BIASNEXT>(R, sa, q);
     }
 }
-// acc[t] (+)= W-chunks * b[0..KS).  The first chunk's aux KB holds the layer's bias (when BIAS): it initialises the
-// accumulators (position i of quad block qb <- bias[feat(qb, g, i)]).
+// acc[t] (+)= W-chunks * b[0..KS).  ZERO: the sum starts at zero (the first k-step's products take C = 0); BIAS: the LAST
+// chunk's aux KB holds the layer's bias, added when the sum is complete (position i of quad block qb <- bias[feat(qb, g, i)]),
+// like the reference's addmm (models/pano_mip_nerf.py:95-114).
 //
 // NP = 2 works in scaled units: the weights of the GEMM carry 2^wexp and the B operand of this lane's sample 2^bex, so
 // the MFMAs accumulate 2^sc times the true sums (sc = wexp + bex, per lane: an accumulator register belongs to ONE
-// sample).  Bias / running sums enter multiplied by 2^sc and the result leaves divided by it: exact (powers of two).
+// sample).  A running sum enters multiplied by 2^sc and the result leaves divided by it: exact (powers of two); with a bias
+// the division and the addition are ONE fma per element (the bias used to enter the sum scaled, 64 v_ldexp per layer, and
+// the result left through 64 more).
 template <int NP, int KS, int NT, bool BIAS, bool ZERO, bool BIASNEXT = false>
 __device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS], accv (&acc)[NT], int lane, int sc = 0) {
     constexpr int CF = Cfg<NP>::CF;
     static_assert(Look<NP>::N <= Cfg<NP>::PER, "the look-ahead stays within one chunk boundary");
     const uint32_t s0 = R.acquire();
-    if constexpr (BIAS) {
-        const float* aux = reinterpret_cast<const float*>(R.lds + (s0 - R.lds_addr) + CF * 1024) + 4 * (lane / TILE);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < ACCQ; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(aux + QB * (ACCQ * t + q));
-                acc[t][4 * q] = NP == 2 ? ldexpf(v[0], sc) : v[0];
-                acc[t][4 * q + 1] = NP == 2 ? ldexpf(v[1], sc) : v[1];
-                acc[t][4 * q + 2] = NP == 2 ? ldexpf(v[2], sc) : v[2];
-                acc[t][4 * q + 3] = NP == 2 ? ldexpf(v[3], sc) : v[3];
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not see the asm reads that follow
-    } else if constexpr (ZERO) {
-        // (the first k-step's products take C = 0: see GemmStep)
-    } else if constexpr (NP == 2) {
+    if constexpr (!ZERO && NP == 2) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -605,7 +611,22 @@ __device__ __forceinline__ void chain_gemm(Ring<NP>& R, const BFrag<NP> (&b)[KS]
     BFrag<NP> q[Look<NP>::N];
     gemm_prologue<NP, KS * NT, 0, BIASNEXT>(R, sa, q);
     GemmStep<NP, KS, NT, 0, BIASNEXT, ZERO>::run(R, b, acc, sa, q, lane);
-    if constexpr (NP == 2) {
+    if constexpr (BIAS) {
+        // (sa: the GEMM's last chunk; its slot is refilled only behind the barrier of the NEXT acquire)
+        const float* aux = reinterpret_cast<const float*>(R.lds + ((sa - lane * 16) - R.lds_addr) + CF * 1024) + 4 * (lane / TILE);
+        const float inv = NP == 2 ? ldexpf(1.0f, -sc) : 1.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int qd = 0; qd < ACCQ; ++qd) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(aux + QB * (ACCQ * t + qd));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x = acc[t][4 * qd + i];
+                    acc[t][4 * qd + i] = NP == 2 ? __builtin_fmaf(x, inv, v[i]) : x + v[i];
+                }
+            }
+    } else if constexpr (NP == 2) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -791,29 +812,48 @@ __device__ __forceinline__ void store_t(TE* base, const accv (&acc)[NT]) {
         }
 }
 
-// ReLU gate bits of a lane: bit 4 qb + i, (NT * ACCQ) / 8 words (up to 4).  Seen from the B operand, the 8 elements of
-// k-step ks of the same lane are byte ks of these bytes.
-constexpr int MW = 4 / (NG / 2);  // gate words per lane for a 256-wide vector: 4 (TILE 32) or 2 (TILE 16)
+// ReLU gate bits of a lane, MW words (4 with TILE 32, 2 with TILE 16): element j of k-step ks of the lane's B operand is half
+// j & 1 of dword d = 4 ks + (j >> 1) of its packed planes, and its gate is bit (d & 15) + 16 (j & 1) of word d >> 4.  Seen
+// from an accumulator, position i of quad block qb is element 4 (qb & 1) + i of k-step qb >> 1.
+constexpr int MW = 4 / (NG / 2);  // gate words per lane for a 256-wide vector
+__host__ __device__ constexpr int gate_word(int ks, int j) { return (4 * ks + (j >> 1)) >> 4; }
+__host__ __device__ constexpr int gate_bit(int ks, int j) { return ((4 * ks + (j >> 1)) & 15) + 16 * (j & 1); }
 struct Gate {
     uint32_t w[MW];
 };
-__device__ __forceinline__ uint32_t bit_of(float v) {  // v >= 0: 1 if v > 0
-    const uint32_t u = __builtin_bit_cast(uint32_t, v);
-    return u < 1u ? u : 1u;
-}
 template <int NT>
-__device__ __forceinline__ void relu_bits(accv (&acc)[NT], Gate& g) {
+__device__ __forceinline__ void relu(accv (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < ACCR; ++e) {
+            const float x = acc[t][e];
+            acc[t][e] = fmaxf(x, 0.f);
+        }
+}
+// The gate words of a ReLU output from the LEADING plane of its B operand: an element is alive iff its leading 16-bit term
+// is not zero (the term of a non-negative value is a non-negative half: min(bits, 1) as an unsigned 16-bit integer is the
+// gate) - one packed minimum and one shift-or per TWO elements, where a compare, a select and an or per element stood.
+// (A positive value whose leading term rounds to zero lies 2^-40 below its sample's largest activation with the fp16 pair,
+// below 2^-133 with bf16: it counts as dead, in the forward chain - whose next operand holds a zero there - and in every
+// backward pass alike.)
+template <int NP, int KS, int KB>
+__device__ __forceinline__ void gate_words(const BFrag<NP> (&b)[KB], Gate& g) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < MW; ++i) g.w[i] = 0u;
+    const u16x2 one = {1, 1};
 #pragma unroll
-    for (int qb = 0; qb < NT * ACCQ; ++qb)
+    for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 h = __builtin_bit_cast(u32x4, b[ks].p[0]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x = AQ(acc, qb, i);
-            const float v = fmaxf(x, 0.f);
-            AQ(acc, qb, i) = v;
-            g.w[(4 * qb + i) >> 5] |= bit_of(v) << ((4 * qb + i) & 31);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t hq = h[q];
+            const u16x2 m = __builtin_elementwise_min(__builtin_bit_cast(u16x2, hq), one);
+            g.w[(4 * ks + q) >> 4] |= __builtin_bit_cast(uint32_t, m) << ((4 * ks + q) & 15);
         }
+    }
 }
 template <int NT>
 __device__ __forceinline__ void gate_bits(accv (&acc)[NT], const Gate& g) {
@@ -821,7 +861,8 @@ __device__ __forceinline__ void gate_bits(accv (&acc)[NT], const Gate& g) {
     for (int qb = 0; qb < NT * ACCQ; ++qb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = __builtin_amdgcn_sbfe((int)g.w[(4 * qb + i) >> 5], (4 * qb + i) & 31, 1);  // 0 or -1
+            const int ks = qb >> 1, j = 4 * (qb & 1) + i;
+            const int m = __builtin_amdgcn_sbfe((int)g.w[gate_word(ks, j)], gate_bit(ks, j), 1);  // 0 or -1
             const float x = AQ(acc, qb, i);  // (a bit_cast applied directly to the vector element reads element 0)
             AQ(acc, qb, i) = __int_as_float(__float_as_int(x) & m);
         }
@@ -1068,6 +1109,23 @@ __device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, typ
     return acc_to_b<NP, NT_H, KS_H>(acc, bh, 0.f, EXP_CAP_Z);  // (backward-direction and tangent sweeps only)
 }
 
+// pos_enc of the view directions (models/mip.py:431-441: [x | sin(x 2^l) | sin(x 2^l + pi/2)], l < 4) per view row, padded to
+// 32 features: feature v < 3 is the direction, 3 <= v < 27 the sines, the rest zero.
+__global__ void k_view_table(int64_t view_rows, const float* viewdirs, float* tab) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= view_rows * 32) return;
+    const int64_t r = idx >> 5;
+    const int v = (int)(idx & 31);
+    const float vd0 = viewdirs[r * 3], vd1 = viewdirs[r * 3 + 1], vd2 = viewdirs[r * 3 + 2];
+    auto vsel = [&](int ch) { return ch == 0 ? vd0 : (ch == 1 ? vd1 : vd2); };
+    const int i = v - 3, half = i >= 12 ? 1 : 0;
+    int l, ch;
+    level_of(i < 0 ? 0 : i - 12 * half, l, ch);
+    const float xb = vsel(ch) * pow2i(l & 3);
+    const float sv = fast_sin(half ? xb + HALF_PI_F : xb);
+    tab[idx] = v < 3 ? vsel(v) : (v < PN_VIEW_DIM ? sv : 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------- forward chain
 struct FwdArgs {
     int64_t M, nst;        // sample rows, workgroup tiles of CH_SAMPLES
@@ -1079,6 +1137,7 @@ struct FwdArgs {
     const float* mean;     // [M,3]
     const float* cov;      // [M,3]
     const float* viewdirs; // [view_rows,3]
+    float* view_tab;       // [view_rows,32]: the view encoding of every view row (27 features + zeros), built by k_view_table
     float* enc_t;          // T [96]
     float* acts_t;         // T: h0..h7 [256] x 8, then bottleneck + view encoding [288], then view hidden [128]; null: not kept
     uint32_t* masks;       // [9][Mp][8]
@@ -1097,6 +1156,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
+    chain_prio(wid);
     Ring<NP> R;
     R.start(a.pack, lds, fwd_chunk0<NP>(F_COUNT), wid, lane, 0);
     RunMax<10> RM;  // activation slots 0..9
@@ -1133,14 +1193,15 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
 #endif
             bex = encode<NP, 0>(mu, cv, zero3, T.g, et, benc).ex;
             TR(1);
-            chain_gemm<NP, KS_ENC, NT_H, true, false, true>(R, benc, acc, lane, wx(F_L0) + bex);
+            chain_gemm<NP, KS_ENC, NT_H, true, true, true>(R, benc, acc, lane, wx(F_L0) + bex);
             TR(2);
         }
-        auto finish_hidden = [&](int slot) {  // ReLU, gate bits, T store, next B operand
-            relu_bits<NT_H>(acc, mw);
+        auto finish_hidden = [&](int slot) {  // ReLU, T store, next B operand, gate bits
+            relu<NT_H>(acc);
             if (TP(a.acts_t)) store_t<NT_H>(TP(a.acts_t) + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);  // (uniform)
-            store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
             const Ex e = acc_to_b<NP, NT_H, KS_H>(acc, bh);
+            gate_words<NP, KS_H, KS_H>(bh, mw);
+            store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
             bex = e.ex;
             RM.upd(slot, e.top);
         };
@@ -1148,30 +1209,30 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         TR(3);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
-            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_L0 + l) + bex);
+            chain_gemm<NP, KS_H, NT_H, true, true, true>(R, bh, acc, lane, wx(F_L0 + l) + bex);
             TR(2 + 2 * l);
             finish_hidden(l);
             TR(3 + 2 * l);
         }
         {  // ---- layer 5: [h4 | enc] as two accumulating GEMMs (F_L5, F_L5E)
-            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_L5) + bex);
+            chain_gemm<NP, KS_H, NT_H, false, true, true>(R, bh, acc, lane, wx(F_L5) + bex);  // (the bias comes with F_L5E)
             BFrag<NP> benc[KS_ENC];
             const int eex = reload_b<NP, KS_ENC>(et, benc);
-            chain_gemm<NP, KS_ENC, NT_H, false, false, true>(R, benc, acc, lane, wx(F_L5E) + eex);
+            chain_gemm<NP, KS_ENC, NT_H, true, false, true>(R, benc, acc, lane, wx(F_L5E) + eex);
             TR(12);
             finish_hidden(5);
             TR(13);
         }
 #pragma unroll 1
         for (int l = 6; l <= 7; ++l) {
-            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_L6 + l - 6) + bex);
+            chain_gemm<NP, KS_H, NT_H, true, true, true>(R, bh, acc, lane, wx(F_L6 + l - 6) + bex);
             TR(2 + 2 * l);
             finish_hidden(l);
             TR(3 + 2 * l);
         }
         {  // ---- density head (one tile; channel ch is feature ch: quad block 0 of lane group ch / 4)
             accv ad[1];
-            chain_gemm<NP, KS_H, 1, true, false, true>(R, bh, ad, lane, wx(F_DEN) + bex);
+            chain_gemm<NP, KS_H, 1, true, true, true>(R, bh, ad, lane, wx(F_DEN) + bex);
             if (T.live) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1185,35 +1246,27 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         BFrag<NP> bv[KS_H + KS_PAD];
         int vex;
         {
-            chain_gemm<NP, KS_H, NT_H, true, false, true>(R, bh, acc, lane, wx(F_EXTRA) + bex);
+            chain_gemm<NP, KS_H, NT_H, true, true, true>(R, bh, acc, lane, wx(F_EXTRA) + bex);
             TR(19);
             TE* bt = a.acts_t ? TP(a.acts_t) + act_off(8, Mp) + T.blk * (288 * TILE) + T.lo : nullptr;
             if (bt) store_t<NT_H>(bt, acc);
             const Ex e = acc_to_b<NP, NT_H, KS_H + KS_PAD>(acc, bv, 1.0f);  // the view encoding appended below is <= 1
             vex = e.ex;
             RM.upd(8, e.top);
-            const int64_t vr = (T.rc / a.rows_per_ray) % a.view_rows;
-            // (three scalars, not an array: with `float vd[3]` the selects below became a run-time index into a scratch
-            // copy - eight scratch loads per tile, each behind a vmcnt(0) that also waits for the weight ring's DMA)
-            float vd0 = a.viewdirs[vr * 3], vd1 = a.viewdirs[vr * 3 + 1], vd2 = a.viewdirs[vr * 3 + 2];
-            asm volatile("" : "+v"(vd0), "+v"(vd1), "+v"(vd2));
-            auto vsel = [&](int ch) { return ch == 0 ? vd0 : (ch == 1 ? vd1 : vd2); };
-            const int g4 = 4 * opaque(T.g);
+            // the view encoding is a function of the view row (128 samples of a ray share it): read from the per-row table
+            // (it used to be evaluated per sample here - 8 sines per lane, a third of this block's time)
+            const float* vt = a.view_tab + ((T.rc / a.rows_per_ray) % a.view_rows) * 32 + 4 * T.g;
 #pragma unroll
             for (int q = 0; q < KS_PAD; ++q) {
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int v = QB * (2 * q + (j >> 2)) + g4 + (j & 3);  // view-encoding feature 0..31 (27 real)
-                    // features 3..26: sin(x 2^l) for l < 4, then sin(x 2^l + pi/2); branch-free (see opaque())
-                    const int i = v - 3, half = i >= 12 ? 1 : 0;
-                    int l, ch;
-                    level_of(i < 0 ? 0 : i - 12 * half, l, ch);
-                    const float xb = vsel(ch) * pow2i(l & 3);
-                    const float sv = fast_sin(half ? xb + HALF_PI_F : xb);
-                    const float o = v < 3 ? vsel(v) : (v < PN_VIEW_DIM ? sv : 0.f);
-                    x[j] = o;
-                    if (bt) bt[(256 + QB * (2 * q + (j >> 2)) + (j & 3)) * TILE] = (TE)o;
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(vt + QB * (2 * q + h));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        x[4 * h + i] = v[i];
+                        if (bt) bt[(256 + QB * (2 * q + h) + i) * TILE] = (TE)v[i];
+                    }
                 }
                 split_into<NP>(x, bv[KS_H + q], vex);
             }
@@ -1223,20 +1276,21 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         int cex;
         {
             accv av[NT_C];
-            chain_gemm<NP, KS_H + KS_PAD, NT_C, true, false, true>(R, bv, av, lane, wx(F_VIEW) + vex);
+            chain_gemm<NP, KS_H + KS_PAD, NT_C, true, true, true>(R, bv, av, lane, wx(F_VIEW) + vex);
             TR(21);
             Gate w4;
-            relu_bits<NT_C>(av, w4);
+            relu<NT_C>(av);
             if (TP(a.acts_t)) store_t<NT_C>(TP(a.acts_t) + act_off(9, Mp) + T.blk * (128 * TILE) + T.lo, av);
-            store_gate(a.masks, 8, Mp, T.blk * TILE + T.c, T.g, w4);
             const Ex e = acc_to_b<NP, NT_C, KS_C>(av, bc);
+            gate_words<NP, KS_C, KS_C>(bc, w4);
+            store_gate(a.masks, 8, Mp, T.blk * TILE + T.c, T.g, w4);
             cex = e.ex;
             RM.upd(9, e.top);
         }
         TR(22);
         {
             accv ac[1];
-            chain_gemm<NP, KS_C, 1, true, false, true>(R, bc, ac, lane, wx(F_COLOR) + cex);
+            chain_gemm<NP, KS_C, 1, true, true, true>(R, bc, ac, lane, wx(F_COLOR) + cex);
             TR(23);
             if (T.live && T.g == 0) {
 #pragma unroll
@@ -1284,6 +1338,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
+    chain_prio(wid);
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
     RunMax<8> RM;  // r_0..r_7
@@ -1333,7 +1388,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int j = 4 * h + i;
-                        const uint32_t bit = (m7.w[(8 * ks + j) >> 5] >> ((8 * ks + j) & 31)) & 1u;
+                        const uint32_t bit = (m7.w[gate_word(ks, j)] >> gate_bit(ks, j)) & 1u;
                         x[j] = bit ? sgm * wv[i] : 0.f;
                         if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = (TE)x[j];
                     }
@@ -1378,6 +1433,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
+    chain_prio(wid);
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
     RunMax<9> RM;  // hdot_0..hdot_7, edot
@@ -1490,6 +1546,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t Mp = a.nst * CH_SAMPLES;
+    chain_prio(wid);
     Ring<NP> R;
     R.start(a.pack, lds, a.nchunk, wid, lane, 0);
     RunMax<12> RM;  // delta_0..7, d bottleneck, d raw_density, d view hidden, d rgb
@@ -1673,7 +1730,7 @@ __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<N
 }
 // the T tensors are read once per GEMM: non-temporal loads (4.70 -> 4.57 ms for the GEMMs of one evaluation)
 #define WG_LD(p) __builtin_nontemporal_load(p)
-template <int NP, int TM, int TN, int WM, int WN>
+template <int NP, int TM, int TN, int WM, int WN, bool OPP = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NTH = 64 * WM * WN, TMW = 32 * TM * WM, TNW = 32 * TN * WN;
     constexpr int PX = TMW * 16, PY = TNW * 16;     // bf16 elements per plane
@@ -1865,19 +1922,62 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             compute(K % 2);
         }
     };
+    // OPP: the two waves of a SIMD (w and w + NW / 2) take the two phases of a half block in OPPOSITE order - the first half
+    // of the workgroup stages half block h + 1 and then multiplies half block h, the second half multiplies first and
+    // stages after - so that one partner's conversions, LDS writes and global loads run under the other's matrix products
+    // (with every wave in the same phase the kernel ran stage -> barrier -> products, the matrix cores idle during the
+    // former: 47 % busy).  Still two LDS buffers and ONE barrier per half block: products of h read buffer h % 2, which
+    // everyone staged before the previous barrier; the stage of h + 1 overwrites buffer (h + 1) % 2, last read by the
+    // products of h - 1, which everyone finished before the previous barrier.
+    auto one_opp = [&](auto kc, int64_t h) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
+        if (h + K < h1) {  // (uniform)
+            const bool more = h + K + 1 < h1;
+            if (wid < WM * WN / 2) {
+                if (more) {
+                    stage((K + 1) % 2, (K + 1) % NSET);
+                    if (h + K + 1 + NSET < h1) load(h + K + 1 + NSET, (K + 1) % NSET);
+                }
+                compute(K % 2);
+            } else {
+                compute(K % 2);
+                if (more) {
+                    stage((K + 1) % 2, (K + 1) % NSET);
+                    if (h + K + 1 + NSET < h1) load(h + K + 1 + NSET, (K + 1) % NSET);
+                }
+            }
+            __syncthreads();
+        }
+    };
     if (h0 < h1) {
 #pragma unroll
         for (int k = 0; k < NSET; ++k)
             if (h0 + k < h1) load(h0 + k, k);
         constexpr int TRIP = NSET == 3 ? 6 : 2;
+        if constexpr (OPP) {
+            stage(0, 0);
+            if (h0 + NSET < h1) load(h0 + NSET, 0);
+            __syncthreads();
+        }
         for (int64_t h = h0; h < h1; h += TRIP) {
-            one(std::integral_constant<int, 0>{}, h);
-            one(std::integral_constant<int, 1>{}, h);
-            if constexpr (TRIP == 6) {
-                one(std::integral_constant<int, 2>{}, h);
-                one(std::integral_constant<int, 3>{}, h);
-                one(std::integral_constant<int, 4>{}, h);
-                one(std::integral_constant<int, 5>{}, h);
+            if constexpr (OPP) {
+                one_opp(std::integral_constant<int, 0>{}, h);
+                one_opp(std::integral_constant<int, 1>{}, h);
+                if constexpr (TRIP == 6) {
+                    one_opp(std::integral_constant<int, 2>{}, h);
+                    one_opp(std::integral_constant<int, 3>{}, h);
+                    one_opp(std::integral_constant<int, 4>{}, h);
+                    one_opp(std::integral_constant<int, 5>{}, h);
+                }
+            } else {
+                one(std::integral_constant<int, 0>{}, h);
+                one(std::integral_constant<int, 1>{}, h);
+                if constexpr (TRIP == 6) {
+                    one(std::integral_constant<int, 2>{}, h);
+                    one(std::integral_constant<int, 3>{}, h);
+                    one(std::integral_constant<int, 4>{}, h);
+                    one(std::integral_constant<int, 5>{}, h);
+                }
             }
         }
     }
@@ -1923,11 +2023,11 @@ static PackTable fwd_table(int nc) {
         PackLayer& L = T.L[i];
         const int KS = fwd_ks(i), NT = fwd_nt(i);
         fill_layer(L, fwd_chunk0<NP>(i), KS, NT, TILE * NT);
-        if (i == F_L5) {  // hidden columns of layer 5 (+ its bias); the skip columns follow as F_L5E
+        if (i == F_L5) {  // hidden columns of layer 5; the skip columns follow as F_L5E, which completes the sum (+ bias)
             add_seg(L, P.w[5], ld5, 0, PN_WIDTH, 0, 0);
-            L.aux_off = P.b[5]; L.aux_n = PN_WIDTH;
         } else if (i == F_L5E) {
             add_seg(L, P.w[5], ld5, 0, PN_ENC_DIM, 0, PN_WIDTH);
+            L.aux_off = P.b[5]; L.aux_n = PN_WIDTH;
         } else if (i <= F_L7) {
             const int l = i < F_L5E ? i : i - 1;
             const int k = (l == 0) ? PN_ENC_DIM : PN_WIDTH;
@@ -2131,7 +2231,11 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     {
     PnProfScope prof(6 + j.cfg, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone (not the slab reduction)
     switch (j.cfg) {
+#ifdef PN_WGRAD_OPP
+        case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2, (NP == 2)>), grid, dim3(512), 0, s, a); break;
+#else
         case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a); break;
+#endif
         case 1: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 8, 1>), grid, dim3(512), 0, s, a); break;
         // (128 x 288 by twelve waves of 1 x 3 tiles: as four waves of 1 x 9 it held 392 registers per lane - one wave per
         // SIMD, two register sets in flight - and ran 3.8 TB/s)
@@ -2176,11 +2280,11 @@ int64_t pn_chain_acts_floats(int64_t M) { return acts_floats(pn_pad(M)); }
 int pn_chain_amax_slots(void) { return AM_COUNT; }
 
 int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int planes, const void* pack,
-                     const float* mean, const float* cov, const float* viewdirs, float* enc_t, float* acts_t,
+                     const float* mean, const float* cov, const float* viewdirs, float* view_tab, float* enc_t, float* acts_t,
                      uint32_t* masks, float* raw_rgb, float* raw_den, uint32_t* amax, void* stream) {
     if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
-    if (!pack || !mean || !cov || !viewdirs || !enc_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;  // acts_t may be null
+    if (!pack || !mean || !cov || !viewdirs || !view_tab || !enc_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;  // acts_t may be null
     FwdArgs a{};
     a.M = M;
     a.nst = pn_pad(M) / CH_SAMPLES;
@@ -2191,7 +2295,10 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
     a.pack = (const unsigned char*)pack;
     a.wexp = reinterpret_cast<const int*>(a.pack + g.bytes);
-    a.mean = mean; a.cov = cov; a.viewdirs = viewdirs;
+    a.mean = mean; a.cov = cov; a.viewdirs = viewdirs; a.view_tab = view_tab;
+    hipLaunchKernelGGL(k_view_table, dim3((unsigned)((view_rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, view_rows,
+                       viewdirs, view_tab);
+    PN_CHECK_LAUNCH();
     a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
     a.amax = planes == 2 ? amax : nullptr;
     if (a.amax) {

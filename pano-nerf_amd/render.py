@@ -38,6 +38,7 @@ class _Eval:
         self.mean, self.cov = e(M, 3), e(M, 3)
         if planes:
             self.enc = e(Mp * 96)                                          # T [96]
+            self.viewtab = e(self.view_rows * 32)                          # view encoding per view row (scratch of the forward)
             # T h0..h7, bottleneck | viewenc, view hidden — only the backward re-reads them: not kept in inference
             self.acts = e(int(_lib.load().pn_chain_acts_floats(M))) if keep else None
             # planes = 2, training: largest |x| of every T tensor (one power-of-two scale per tensor in the weight gradients)
@@ -72,7 +73,8 @@ class _Cfg:
 def _mlp_forward(ev, params, wpack, st):
     if ev.planes:
         _lib.call("pn_chain_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, ev.planes, wpack.data_ptr(),
-                  ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), _lib.ptr(ev.acts),
+                  ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.viewtab.data_ptr(), ev.enc.data_ptr(),
+                  _lib.ptr(ev.acts),
                   ev.masks.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), _lib.ptr(ev.amax), st)
         return
     _lib.call("pn_mlp_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, params.data_ptr(), wpack.data_ptr(),

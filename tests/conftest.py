@@ -80,49 +80,63 @@ def pytest_terminal_summary(terminalreporter):
 FIRST_ORDER_TENSORS = ("extra_layer", "view_layers", "color_layer")
 
 
-def gates_of(ev, fused):
-    """[9, M, 256] boolean ReLU gates of one MLP evaluation, decoded from the bit words the kernels wrote (test hook:
-    `model.mlp.debug_keep = True` keeps the evaluation buffers of the last forward in `model.mlp.debug_pack`)."""
+def gates_of(ev, fused, rows=None):
+    """[9, M, 256] boolean ReLU gates of one MLP evaluation (or of its sample rows `rows`), decoded from the bit words the
+    kernels wrote (test hook: `model.mlp.debug_keep = True` keeps the evaluation buffers of the last forward in
+    `model.mlp.debug_pack`)."""
     import torch
     M = ev.M
-    words = ev.masks[:, :M].to(torch.int64) & 0xffffffff  # [9, M, 8]
+    masks = ev.masks[:, :M] if rows is None else ev.masks[:, rows.to(ev.masks.device)]
+    words = masks.to(torch.int64) & 0xffffffff  # [9, M, 8]
     f = torch.arange(256, device=words.device)
-    if fused:  # pn_chain.hip: lane group g = (f % QB) / 4 holds bit 4 (f / QB) + f % 4 of its 8 / NG words, QB = 4 NG, NG = 64 / tile
+    if fused:  # pn_chain.hip (gate_word / gate_bit): feature f = position i of quad block qb of lane group g (QB = 4 NG features
+        # per quad block, NG = 64 / tile) is element j = 4 (qb & 1) + i of k-step qb >> 1 of the lane's B operand, i.e. half
+        # j & 1 of its packed dword d = 4 (qb >> 1) + (j >> 1): bit (d & 15) + 16 (j & 1) of the group's word d >> 4
         from pano_nerf_amd import _lib
         tile = int(_lib.load().pn_chain_tile())
         ng = 64 // tile
         qb_size = 4 * ng
         qb, g, i = f // qb_size, (f % qb_size) // 4, f % 4
-        bitpos = 4 * qb + i
-        w, bit = g * (8 // ng) + (bitpos >> 5), bitpos & 31
+        j = 4 * (qb & 1) + i
+        d = 4 * (qb >> 1) + (j >> 1)
+        w, bit = g * (8 // ng) + (d >> 4), (d & 15) + 16 * (j & 1)
     else:      # word col / 32, bit c * 8 + i for column 32 (col / 32) + 4 i + c (pn_common.h)
         w, bit = f >> 5, (f & 3) * 8 + ((f & 31) >> 2)
     return ((words[:, :, w] >> bit) & 1).bool().cpu()
 
 
-def forced_gate_sets(model, normals, surf):
+def forced_gate_sets(model, normals, surf, rays=None, n=None, env_rows_per_ray=100):
     """The gate decisions of the model's last forward in the order the oracle's mlp_forward calls consume them: level 0,
-    level 1, (level-1 normals), (env light)."""
+    level 1, (level-1 normals), (env light).  `rays` (int64 indices) + `n` (samples per ray): only those rays' sample rows."""
+    import torch
     pack = model.mlp.debug_pack
     fused = model.mlp_mode != "layerwise"
-    g0, g1 = gates_of(pack[5], fused), gates_of(pack[6], fused)
+    r01 = re = None
+    if rays is not None:
+        r01 = (rays[:, None] * n + torch.arange(n)[None]).reshape(-1)
+        re = (rays[:, None] * env_rows_per_ray + torch.arange(env_rows_per_ray)[None]).reshape(-1)
+    g0, g1 = gates_of(pack[5], fused, r01), gates_of(pack[6], fused, r01)
     sets = [g0, g1]
     if normals:
         sets.append(g1)
     if surf:
-        sets.append(gates_of(pack[7], fused))
+        sets.append(gates_of(pack[7], fused, re))
     return sets
 
 
-def check_flat_grad_pointwise(flat_grad, ref_by_name, nc, tol=1e-4):
-    """EVERY entry of EVERY tensor of the flat gradient block within `tol` of the tensor's max |reference| — for references
-    computed on the SAME ReLU gate decisions (oracle.forced_gates).  Returns the worst tensor's error."""
+def check_flat_grad_pointwise(flat_grad, ref_by_name, nc, tol=1e-4, ref64_fn=None):
+    """EVERY entry of EVERY tensor of the flat gradient block within `tol` of the tensor's max |reference| - for references
+    computed on the SAME ReLU gate decisions (oracle.forced_gates).  Forcing the gates removes the discontinuity, not every
+    ill-conditioning: a ray whose per-sample normals nearly cancel amplifies fp32 rounding in the fp32 ORACLE too (seen:
+    one near-pole ray of the 257 x 33 case carries half the batch's gradient and is 6e-4 off in every kernel mode, the
+    exact-fp32 one included).  `ref64_fn()` -> the same oracle evaluated in fp64: a tensor beyond `tol` must then be within
+    max(tol, 2 x the fp32 oracle's own error) of the fp64 gradients.  Returns the worst tensor's error."""
     from pano_nerf_amd.mlp import ORDER, param_layout
     offs, total = param_layout(nc)
     order = sorted(ORDER, key=lambda k: offs[k])
     got_all = np.asarray(flat_grad, dtype=np.float64).reshape(-1)
     assert got_all.size == total and np.isfinite(got_all).all()
-    worst = 0.0
+    worst, ref64 = 0.0, None
     for i, k in enumerate(order):
         lo, hi = offs[k], offs[order[i + 1]] if i + 1 < len(order) else total
         r = ref_by_name.get(k)
@@ -131,8 +145,17 @@ def check_flat_grad_pointwise(flat_grad, ref_by_name, nc, tol=1e-4):
             assert float(np.abs(got_all[lo:hi]).max()) <= 1e-12, (k, "expected a zero gradient")
             continue
         e = float(np.abs(got_all[lo:hi] - ref).max()) / float(np.abs(ref).max())
+        if e > tol and ref64_fn is not None:
+            if ref64 is None:
+                ref64 = ref64_fn()
+            r64 = np.asarray(ref64[k], dtype=np.float64).reshape(-1)
+            s64 = float(np.abs(r64).max())
+            ours, theirs = float(np.abs(got_all[lo:hi] - r64).max()) / s64, float(np.abs(ref - r64).max()) / s64
+            assert ours <= max(tol, 2 * theirs), (k, "vs the fp64 oracle on identical gates: ours, the fp32 oracle's own", ours, theirs)
+            e = min(e, ours)
+        else:
+            assert e <= tol, (k, "max |err| / max |ref| on identical gates", e)
         worst = max(worst, e)
-        assert e <= tol, (k, "max |err| / max |ref| on identical gates", e)
     return worst
 
 

@@ -36,12 +36,12 @@ def _loss_grad(params, rays, rgbs, noise, n):
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pano_nerf_amd.dist import allreduce_flat_grad, gather_image, shard_bounds, shard_rays
     flat, rgbs, _, _ = orc.synthetic_scene(8, 16, 3, seed=4)
-    B, N = 12, 8
-    idx = torch.arange(0, B * 5, 5)
+    B, N = (12 if world == 2 else 2 * world), 8
+    idx = torch.arange(0, B * 5, 5) % flat.origins.shape[0]
     rays = orc.Rays(*[x[idx] for x in flat])
     gen = torch.Generator().manual_seed(3)
     noise = dict(t_rand=torch.rand(B, N + 1, generator=gen), u_rand=torch.rand(B, N + 1, generator=gen) * (1 / (N + 1) - 1.2e-7))
@@ -60,12 +60,15 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_gradient_equals_global_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_gradient_equals_global_batch(tmp_path, world):
+    """world 8 = the rank count of the BASELINE scaling run (train.py:86-92 under DDP): eight gloo ranks on the CPU."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    rel, rows, first_sum, second_mean = np.load(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rel, rows, first_sum, rest_mean = np.load(tmp_path / "res.npy")
     assert rel < 1e-5, rel            # equal shards + lossmult == 1: mean of shard gradients = global gradient
-    assert rows == 12 and first_sum == 0.0 and second_mean == 1.0
+    B = 12 if world == 2 else 2 * world
+    assert rows == B and first_sum == 0.0 and rest_mean == np.mean(np.arange(1, world))
 
 
 def test_shard_bounds_cover_everything():

@@ -87,8 +87,8 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc, pla
     rr, rd = E(M, 3), E(M, nc)
     amax = torch.empty(int(lib.pn_chain_amax_slots()), dtype=torch.int32, device=dev())  # maxima of the T tensors (planes = 2)
     _lib.call("pn_chain_forward", M, rows_per_ray, view_rows, nc, planes, pack.data_ptr(), mean_d.data_ptr(), cov_d.data_ptr(),
-              vd_d.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), ev.masks.data_ptr(), rr.data_ptr(), rd.data_ptr(),
-              amax.data_ptr(), st())
+              vd_d.data_ptr(), E(view_rows * 32).data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), ev.masks.data_ptr(), rr.data_ptr(),
+              rd.data_ptr(), amax.data_ptr(), st())
     torch.cuda.synchronize()
 
     # ---- fp64 model (natural gates): forward values

@@ -49,10 +49,19 @@ def test_ragged_and_tiny_batches_match_oracle(B, N):
     check_flat_grad_per_tensor(g.detach().cpu().numpy(), {k: x.detach().numpy() for k, x in zip(p.keys(), ref_g)}, 5,
                                second_order=True, n_rows=B * (2 * N + 100))
     # pointwise, every entry of every tensor: the oracle on the gate decisions the kernels took
-    with orc.forced_gates(forced_gate_sets(model, normals=True, surf=True)):
+    sets = forced_gate_sets(model, normals=True, surf=True)
+    with orc.forced_gates(sets):
         fl = orc.pano_loss(orc.pano_forward(p, rays_c, env_c, num_samples=N), rays_c.lossmult, rgbs)
         fg = torch.autograd.grad(fl, list(p.values()))
-    check_flat_grad_pointwise(g.detach().cpu().numpy(), {k: x.detach().numpy() for k, x in zip(p.keys(), fg)}, 5)
+
+    def fp64():
+        p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+        r64 = orc.Rays(*[x.double() for x in rays_c])
+        with orc.forced_gates(sets):
+            l64 = orc.pano_loss(orc.pano_forward(p64, r64, env_c, num_samples=N), r64.lossmult, rgbs.double())
+            return {k: x.detach().numpy() for k, x in zip(p64.keys(), torch.autograd.grad(l64, list(p64.values())))}
+
+    check_flat_grad_pointwise(g.detach().cpu().numpy(), {k: x.detach().numpy() for k, x in zip(p.keys(), fg)}, 5, ref64_fn=fp64)
 
 
 def test_maximum_sample_count():
@@ -105,6 +114,32 @@ def test_device_ray_pool():
     env = pool.lit_rays(10)
     assert env.directions.dtype == torch.float16 and env.directions.shape == (10, 3)
     assert abs(float(env.lossmult[0, 0]) - 4 * np.pi / 10) < 2e-3
+
+
+def test_optimizer_step_between_forward_and_backward_raises():
+    """FlatAdam writes the flat parameter block through raw device pointers (no autograd version bump): a backward whose
+    forward saw the older weights must refuse instead of mixing them with the saved activations."""
+    import pano_nerf_amd as pn
+    rays_c, rgbs, radius = scene_rays(16)
+    rays = pn.Rays(*[x.to(dev()) for x in rays_c])
+    env = pn.generate_lit_rays(10, radius)
+    model = pn.PanoMipNeRF(num_samples=8, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5).to(dev())
+    opt = pn.FlatAdam(model.mlp, lr=1e-3)
+    for stepper in ("step", "step_dev"):
+        outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+        loss, _ = pn.pano_loss(outs, rays.lossmult, rgbs.to(dev()))
+        g = torch.ones_like(model.mlp.flat_params())
+        if stepper == "step":
+            opt.step(g)
+        else:
+            opt.step_dev(g, torch.full((1,), 1e-3, device=dev()))
+        with pytest.raises(RuntimeError, match="modified in place"):
+            loss.backward()
+    # and the ordinary order still works
+    outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    loss, _ = pn.pano_loss(outs, rays.lossmult, rgbs.to(dev()))
+    loss.backward()
+    opt.step()
 
 
 CONFIGS = [
@@ -171,17 +206,24 @@ def test_assorted_configurations_match_oracle(cfg):
                                n_rows=B * (2 * N + (100 if (kind == "pano" and surf) else 0)))
     # pointwise, every entry of every tensor: the oracle on the gate decisions the kernels took (these cases run up to
     # 42 k MLP rows, where a rank-stripped comparison would hide errors of rank up to 64)
-    with orc.forced_gates(forced_gate_sets(model, normals=(kind == "pano" or bool(ort)), surf=(kind == "pano" and bool(surf)))):
-        if kind == "pano":
-            fl = orc.pano_loss(orc.pano_forward(p, rays_c, orc.Rays(*[x.cpu() for x in env]), num_samples=N, white_bkgd=white,
-                                                enable_surf=surf, use_ort_loss=ort, noise=noise), rays_c.lossmult, rgbs, surface=surf)
-        else:
-            fl = orc.mip_loss(orc.mip_forward(p, rays_c, num_samples=N, white_bkgd=white, use_ort_loss=ort, noise=noise),
-                              rays_c.lossmult, rgbs, use_ort=ort)
-        fg = torch.autograd.grad(fl, list(p.values()), allow_unused=True)
-    check_flat_grad_pointwise(g.detach().cpu().numpy(),
-                              {k: (None if x is None else x.detach().numpy()) for k, x in zip(p.keys(), fg)},
-                              5 if kind == "pano" else 1)
+    sets = forced_gate_sets(model, normals=(kind == "pano" or bool(ort)), surf=(kind == "pano" and bool(surf)))
+
+    def forced(dt):
+        q = {k: v.to(dt).requires_grad_(True) for k, v in params.items()}
+        rc = orc.Rays(*[x.to(dt) for x in rays_c])
+        nz = None if noise is None else {k: v.to(dt) for k, v in noise.items()}
+        with orc.forced_gates(sets):
+            if kind == "pano":
+                fl = orc.pano_loss(orc.pano_forward(q, rc, orc.Rays(*[x.cpu() for x in env]), num_samples=N, white_bkgd=white,
+                                                    enable_surf=surf, use_ort_loss=ort, noise=nz), rc.lossmult, rgbs.to(dt), surface=surf)
+            else:
+                fl = orc.mip_loss(orc.mip_forward(q, rc, num_samples=N, white_bkgd=white, use_ort_loss=ort, noise=nz),
+                                  rc.lossmult, rgbs.to(dt), use_ort=ort)
+            fg = torch.autograd.grad(fl, list(q.values()), allow_unused=True)
+        return {k: (None if x is None else x.detach().numpy()) for k, x in zip(q.keys(), fg)}
+
+    check_flat_grad_pointwise(g.detach().cpu().numpy(), forced(torch.float32), 5 if kind == "pano" else 1,
+                              ref64_fn=lambda: forced(torch.float64))
 
 
 @pytest.mark.parametrize("mode", ["fused_f16x2", "fused"])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, rel_err
+from conftest import assert_close, forced_gate_sets, rel_err
 from oracle import pano_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -270,6 +270,7 @@ def test_headline_size_matches_oracle_on_a_ray_subset(mode):
     env_c = orc.Rays(*[x.cpu() for x in env])
     model = make_pano(N)
     model.mlp_mode = mode
+    model.mlp.debug_keep = True
     gen = torch.Generator().manual_seed(7)
     noise = dict(t_rand=torch.rand(B, S, generator=gen), u_rand=torch.rand(B, S, generator=gen) * (1.0 / S - 1.2e-7),
                  env_rand=torch.rand(1, 11, generator=gen))
@@ -286,7 +287,9 @@ def test_headline_size_matches_oracle_on_a_ray_subset(mode):
     p = orc.init_params(4, 5)
     with torch.no_grad():
         ref = orc.pano_forward(p, sub_rays, env_c, num_samples=N, noise=sub_noise)
-    flips = 0
+    # (a) the oracle as it stands: well-conditioned outputs at 1e-4 (tensor scale AND element-wise); the outputs derived from
+    # the density gradient (a ReLU gate with a pre-activation of ~1e-7 flips under any fp32 summation order and moves one
+    # ray: with 128 samples a ray a few of the 32 rays sit on such a gate) on the median only
     for lvl in (0, 1):
         for nme, v, r in zip(NAMES9, outs[lvl], ref[lvl]):
             assert (v is None) == (r is None), (lvl, nme)
@@ -295,15 +298,20 @@ def test_headline_size_matches_oracle_on_a_ray_subset(mode):
             got, want = v.detach()[sub.to(dev())].cpu().numpy(), r.numpy()
             key = f"headline/{mode}/l{lvl}/{nme}"
             if nme in LOOSE:
-                # derived from the density gradient: a ReLU gate with a pre-activation of ~1e-7 flips under any fp32 summation
-                # order and moves ONE ray; median at 1e-4 and at most two of the 32 rays beyond 1e-3
                 scale = max(float(np.abs(want).max()), 1e-12)
                 per_ray = np.abs(got - want).reshape(K, -1).max(-1) / scale
                 assert float(np.median(per_ray)) < 1e-4, (key, float(np.median(per_ray)))
-                assert int((per_ray > 1e-3).sum()) <= 2, (key, per_ray)
-                flips = max(flips, int((per_ray > 1e-3).sum()))
             else:
                 assert_close(got, want, key)
+    # (b) the oracle on the gate decisions the kernels took for these rays: EVERY per-ray output pointwise at 1e-4
+    with orc.forced_gates(forced_gate_sets(model, normals=True, surf=True, rays=sub, n=N)), torch.no_grad():
+        refg = orc.pano_forward(p, sub_rays, env_c, num_samples=N, noise=sub_noise)
+    for nme, v, r in zip(NAMES9, outs[1], refg[1]):
+        if v is None or nme == "ort_loss":
+            continue
+        got, want = v.detach()[sub.to(dev())].cpu().numpy(), r.numpy()
+        e = rel_err(got, want)
+        assert e < 1e-4, (f"headline/{mode}/l1/{nme} on identical gates", e)
     # ---- size-independent properties at this size
     (c0, d0, *_), (c1, d1, ort, nrm, alb, _, sf, dif, shd) = outs
     assert torch.allclose(nrm.norm(dim=-1), torch.ones(B, device=dev()), atol=1e-4)

@@ -60,8 +60,9 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     rr2, rd2 = E(M, 3), E(M, nc)
     import os
     keep = os.environ.get("PN_CHECK_NO_ACTS") is None  # PN_CHECK_NO_ACTS=1: time the inference variant (activations not kept)
+    vtab = E(R * 32)
     call = lambda k=True: _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(),
-                                    cov.data_ptr(), vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr() if (k or keep) else None,
+                                    cov.data_ptr(), vd.data_ptr(), vtab.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr() if (k or keep) else None,
                                     masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(), None, st())
     call()
     torch.cuda.synchronize()
@@ -88,8 +89,9 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
         h = t32_to_rows(TS(acts_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
         for f in (0, 5, 37, 100, 131, 255):
             qb, g, i = f // qbs, (f % qbs) // 4, f % 4
-            word = masks_f[l, :M, g * (8 // ng) + ((4 * qb + i) >> 5)].to(torch.int64) & 0xffffffff
-            bit = (word >> ((4 * qb + i) & 31)) & 1
+            d = 4 * (qb >> 1) + ((4 * (qb & 1) + i) >> 1)  # dword of the packed B operand holding the element (pn_chain.hip: gate_word / gate_bit)
+            word = masks_f[l, :M, g * (8 // ng) + (d >> 4)].to(torch.int64) & 0xffffffff
+            bit = (word >> ((d & 15) + 16 * (i & 1))) & 1
             bad += int((bit.bool() != (h[:, f] > 0)).sum())
     print("  gate-bit mismatches (sampled):", bad)
     if reps:

@@ -81,7 +81,7 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     rr2, rd2 = E(M, 3), E(M, nc)
     amax = torch.empty(int(lib.pn_chain_amax_slots()), dtype=torch.int32, device=dev)
     _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
-              vd.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(),
+              vd.data_ptr(), E(R * 32).data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(),
               amax.data_ptr(), st())
     rs_t, gmean2 = E(8, Mp * 256), E(M, 3)
     f_dgrad = lambda: _lib.call("pn_chain_density_grad", M, nc, planes, dbias, params.data_ptr(), pack.data_ptr(), mean.data_ptr(),
