@@ -58,14 +58,19 @@ constexpr int KSTEP = 2 * QB;        // features per k-step of the MFMA
 constexpr int ACCQ = TILE / QB;      // quad blocks per accumulator tile
 constexpr int ACCR = 4 * ACCQ;       // accumulator registers per tile
 #ifndef PN_CHAIN_WAVES
-#define PN_CHAIN_WAVES 4
+#define PN_CHAIN_WAVES (PN_CHAIN_TILE == 16 ? 8 : 4)
 #endif
-// Waves per workgroup.  TILE 32: 4 (one per SIMD, up to 512 registers).  TILE 16: 4 waves of <= 256 registers and a 3-slot
-// ring, so TWO INDEPENDENT workgroups share a CU (one wave of each per SIMD; a workgroup-wide barrier per chunk keeps the
-// waves of ONE workgroup in lockstep, and 8 waves in one workgroup gained nothing).  What the second wave buys is
-// measured, not assumed: timing ablations (PN_ABL_CHAIN) show a kernel's time to be close to the SUM of its MFMA time and
-// of its VALU / store time - a 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles, so the neighbour's
-// epilogue and this wave's products mostly take turns (starting the second workgroup half a layer late changed nothing).
+// Waves per workgroup.  TILE 32: 4 (one per SIMD, up to 512 registers).  TILE 16: waves of <= 256 registers, two per SIMD,
+// either as ONE workgroup of 8 waves with a 5-slot ring (125 KB; the default since round 3) or as TWO INDEPENDENT workgroups
+// of 4 waves with a 3-slot ring each (-DPN_CHAIN_WAVES=4; the round-2 default).  Measured back to back on the same box, three
+// boxes (profiles/r03_experiments.txt): forward 2.38 / 2.30, 2.35 / 2.31, 2.37 / 2.38 ms (two workgroups / one), reverse sweep
+// 1.77 / 1.72, 1.77 / 1.70, 1.86 / 1.76, tangent sweep 1.71 / 1.66, 1.71 / 1.67, 1.85 / 1.79, backward 2.10 / 2.05, 2.16 /
+// 2.09, 2.28 / 2.24: one workgroup is 0-6 % faster and streams every weight chunk into a CU's LDS once instead of twice.
+// (In one workgroup the chunk barrier keeps the two waves of a SIMD in the same phase; in two they drift apart - neither
+// matters: a kernel's time is close to the SUM of its MFMA time and of its VALU / store time either way (timing ablations,
+// PN_ABL_CHAIN) - a 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles, so one wave's epilogue and its
+// partner's products mostly take turns.  Also without effect in the 8-wave form: s_setprio 1 for waves 4-7, a sixth ring
+// slot, 48-KB chunks (half as many barriers).)
 constexpr int CH_WAVES = PN_CHAIN_WAVES;
 constexpr int CH_THREADS = 64 * CH_WAVES;
 constexpr int CH_SAMPLES = CH_WAVES * TILE;                    // samples per workgroup tile
@@ -1691,7 +1696,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
 // vmcnt(0)); four register sets in flight instead of three (4.88 ms: depth is not the limit).  In fact hipcc drains the
 // prefetched sets in front of every staging phase (vmcnt(3), (2), (1), (0): it cannot count the younger loads behind the
 // conditional `load`); a condition-free steady-state loop with a conditional tail gets vmcnt(13)..(10) - and runs 4.67 ms
-// against 4.57 (two sets; three spill): the loop is bound by its conversion + product instruction time, not by latency.)
+// against 4.57 (two sets; three spill): the loop is bound by its conversion + product instruction time, not by latency.
+// Round 3: the second half of the waves ONE barrier interval behind the first (same code, three LDS buffers, so that on every
+// SIMD one wave stages while its partner multiplies): 6.0-6.2 ms against 4.5 (5.3 with s_setprio around the products) - with
+// one multiplying wave per SIMD nothing covers the fragment-read latency at the head of every interval; a barrier that
+// waits for LDS traffic only (not vmcnt) in the loop as it stands: no change (profiles/r03_experiments.txt).)
 struct WSeg {
     const float* X;  // feature 0 of the X sub-range in block 0
     const float* Y;
@@ -1730,7 +1739,7 @@ __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<N
 }
 // the T tensors are read once per GEMM: non-temporal loads (4.70 -> 4.57 ms for the GEMMs of one evaluation)
 #define WG_LD(p) __builtin_nontemporal_load(p)
-template <int NP, int TM, int TN, int WM, int WN, bool OPP = false>
+template <int NP, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NTH = 64 * WM * WN, TMW = 32 * TM * WM, TNW = 32 * TN * WN;
     constexpr int PX = TMW * 16, PY = TNW * 16;     // bf16 elements per plane
@@ -1922,62 +1931,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             compute(K % 2);
         }
     };
-    // OPP: the two waves of a SIMD (w and w + NW / 2) take the two phases of a half block in OPPOSITE order - the first half
-    // of the workgroup stages half block h + 1 and then multiplies half block h, the second half multiplies first and
-    // stages after - so that one partner's conversions, LDS writes and global loads run under the other's matrix products
-    // (with every wave in the same phase the kernel ran stage -> barrier -> products, the matrix cores idle during the
-    // former: 47 % busy).  Still two LDS buffers and ONE barrier per half block: products of h read buffer h % 2, which
-    // everyone staged before the previous barrier; the stage of h + 1 overwrites buffer (h + 1) % 2, last read by the
-    // products of h - 1, which everyone finished before the previous barrier.
-    auto one_opp = [&](auto kc, int64_t h) __attribute__((always_inline)) {
-        constexpr int K = decltype(kc)::value;
-        if (h + K < h1) {  // (uniform)
-            const bool more = h + K + 1 < h1;
-            if (wid < WM * WN / 2) {
-                if (more) {
-                    stage((K + 1) % 2, (K + 1) % NSET);
-                    if (h + K + 1 + NSET < h1) load(h + K + 1 + NSET, (K + 1) % NSET);
-                }
-                compute(K % 2);
-            } else {
-                compute(K % 2);
-                if (more) {
-                    stage((K + 1) % 2, (K + 1) % NSET);
-                    if (h + K + 1 + NSET < h1) load(h + K + 1 + NSET, (K + 1) % NSET);
-                }
-            }
-            __syncthreads();
-        }
-    };
     if (h0 < h1) {
 #pragma unroll
         for (int k = 0; k < NSET; ++k)
             if (h0 + k < h1) load(h0 + k, k);
         constexpr int TRIP = NSET == 3 ? 6 : 2;
-        if constexpr (OPP) {
-            stage(0, 0);
-            if (h0 + NSET < h1) load(h0 + NSET, 0);
-            __syncthreads();
-        }
         for (int64_t h = h0; h < h1; h += TRIP) {
-            if constexpr (OPP) {
-                one_opp(std::integral_constant<int, 0>{}, h);
-                one_opp(std::integral_constant<int, 1>{}, h);
-                if constexpr (TRIP == 6) {
-                    one_opp(std::integral_constant<int, 2>{}, h);
-                    one_opp(std::integral_constant<int, 3>{}, h);
-                    one_opp(std::integral_constant<int, 4>{}, h);
-                    one_opp(std::integral_constant<int, 5>{}, h);
-                }
-            } else {
-                one(std::integral_constant<int, 0>{}, h);
-                one(std::integral_constant<int, 1>{}, h);
-                if constexpr (TRIP == 6) {
-                    one(std::integral_constant<int, 2>{}, h);
-                    one(std::integral_constant<int, 3>{}, h);
-                    one(std::integral_constant<int, 4>{}, h);
-                    one(std::integral_constant<int, 5>{}, h);
-                }
+            one(std::integral_constant<int, 0>{}, h);
+            one(std::integral_constant<int, 1>{}, h);
+            if constexpr (TRIP == 6) {
+                one(std::integral_constant<int, 2>{}, h);
+                one(std::integral_constant<int, 3>{}, h);
+                one(std::integral_constant<int, 4>{}, h);
+                one(std::integral_constant<int, 5>{}, h);
             }
         }
     }
@@ -2231,11 +2197,7 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     {
     PnProfScope prof(6 + j.cfg, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone (not the slab reduction)
     switch (j.cfg) {
-#ifdef PN_WGRAD_OPP
-        case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2, (NP == 2)>), grid, dim3(512), 0, s, a); break;
-#else
         case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a); break;
-#endif
         case 1: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 8, 1>), grid, dim3(512), 0, s, a); break;
         // (128 x 288 by twelve waves of 1 x 3 tiles: as four waves of 1 x 9 it held 392 registers per lane - one wave per
         // SIMD, two register sets in flight - and ran 3.8 TB/s)
