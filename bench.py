@@ -293,9 +293,10 @@ def main():
     # Graph replay pays where the step is launch-latency sensitive: 512 rays per GPU 136.0 k rays/s replayed against 132.8 k
     # eager, nothing at 1024 / 2048 (151 k / 162 k either way) or 4096 (163 k either way): `auto` replays up to 2048 rays per
     # GPU and keeps the 4096-ray run eager, so that its launches are timed live with HIP events inside the timed region;
-    # it falls back to eager launches if capture fails.  (Replayed steps had looked up to 17 % faster for a while - the
-    # library cleared two small tables with hipMemsetAsync, whose graph nodes did not reliably run before the kernels that
-    # accumulate into them: the fast runs were the corrupted ones.  The tables are cleared by a kernel now.)
+    # it falls back to eager launches if capture fails, or if a replayed step does not reproduce an eager one (try_capture).
+    # (Replayed steps had looked up to 17 % faster for a while - the library cleared two small tables with hipMemsetAsync and
+    # some replays ran on uncleared tables: the fast runs were the corrupted ones.  The captured graph did hold the edges
+    # memset -> accumulating kernel (profiles/r03_graph_memset_nodes.txt); the tables are cleared by a kernel now.)
     use_graph = args.graph == "on" or (args.graph == "auto" and nb <= 2048)
     if use_graph:
         try:

@@ -202,9 +202,11 @@ __device__ __forceinline__ int scale_exp(float amax, int cap = EXP_CAP) {
     const int e = EXP_TOP - __builtin_amdgcn_frexp_expf(amax);
     return e > cap ? cap : e;
 }
-// Clears a small table of words.  A kernel, not hipMemsetAsync: inside a replayed HIP graph the 256-byte memset nodes were
-// not reliably ordered before the kernels that accumulate into the table (512-ray steps came out NaN or with a stale
-// scale table in 4 of 14 runs; never with eager launches).
+// Clears a small table of words.  A kernel, not hipMemsetAsync - a WORKAROUND: with 256-byte memset nodes a replayed HIP
+// graph gave NaN or stale-scale steps in 4 of 14 runs of the 512-ray bench (never with eager launches), although the
+// captured graph is a single linear chain in which every memset node has the kernel before it as predecessor and the
+// accumulating kernel as successor (hipGraphGetEdges on the pre-fix tree: profiles/r03_graph_memset_nodes.txt): not a
+// missing dependency, but how replayed memset nodes execute on this runtime (ROCm 7.2).
 __global__ void k_chain_clear(uint32_t* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
 }

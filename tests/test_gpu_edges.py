@@ -229,9 +229,9 @@ def test_assorted_configurations_match_oracle(cfg):
 @pytest.mark.parametrize("mode", ["fused_f16x2", "fused"])
 def test_graph_replay_reproduces_eager_step(mode):
     """A captured training step replayed many times gives the eager step's loss and gradient every time.  (The fp16-pair
-    mode clears two small scale tables per forward; done with hipMemsetAsync, whose graph nodes were not reliably ordered
-    before the kernels that accumulate into the tables, replays came out NaN or with stale scales in 4 of 14 runs of the
-    512-ray bench - the tables are cleared by a kernel now.)"""
+    mode clears two small scale tables per forward; done with hipMemsetAsync, replays came out NaN or with stale scales in 4
+    of 14 runs of the 512-ray bench - although the captured graph had the edges memset -> accumulating kernel
+    (profiles/r03_graph_memset_nodes.txt).  The tables are cleared by a kernel now: a workaround, guarded by this test.)"""
     import pano_nerf_amd as pn
     B, N = 96, 32
     rays_c, rgbs, radius = scene_rays(B)
