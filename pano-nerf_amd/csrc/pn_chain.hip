@@ -657,19 +657,35 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, float s, uint32_
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
 }
+// N pairs at once, one of the four steps for all pairs before the next: every instruction of a pair reads the register the
+// previous one wrote (half-register writes), which costs a wait state (an s_nop 0, as expensive to issue as the FMA) when the
+// two are adjacent - written pair by pair the split ran 3.5 issue slots per element instead of 2.
+template <int N>
+__device__ __forceinline__ void split2_pairs(const float (&x)[2 * N], float s, uint32_t (&h)[N], uint32_t (&l)[N]) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[q]) : "v"(x[2 * q]), "v"(s));
+#pragma unroll
+    for (int q = 0; q < N; ++q) asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[q]) : "v"(x[2 * q + 1]), "v"(s));
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l[q]) : "v"(x[2 * q]), "v"(s), "v"(h[q]));
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[q]) : "v"(x[2 * q + 1]), "v"(s), "v"(h[q]));
+}
 __device__ __forceinline__ float pow2f(int e) { return __int_as_float((127 + e) << 23); }  // -126 <= e <= 127
 template <int NP>
 __device__ __forceinline__ void split_into(const float (&x)[8], BFrag<NP>& f, int ex = 0) {
     if constexpr (NP == 2) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const float s = pow2f(ex);  // (ex = min(15 - frexp exponent, cap <= 120) lies in [-113, 120])
+        uint32_t hq[4], lq[4];
+        split2_pairs<4>(x, s, hq, lq);
         u32x4 h, l;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint32_t hq, lq;
-            split2_pair(x[2 * q], x[2 * q + 1], s, hq, lq);
-            h[q] = hq;
-            l[q] = lq;
+            h[q] = hq[q];
+            l[q] = lq[q];
         }
         f.p[0] = __builtin_bit_cast(f16x8, h);
         f.p[1] = __builtin_bit_cast(f16x8, l);
@@ -695,10 +711,39 @@ struct Ex {
     uint32_t top;
 };
 // largest |x| of this lane's SAMPLE from the largest |x| this lane holds of it (the lane groups of a column are reduced)
-__device__ __forceinline__ float col_max(float m) {
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    if constexpr (NG == 4) m = fmaxf(m, __shfl_xor(m, 16, 64));
-    return m;
+// (v_permlane32_swap / v_permlane16_swap: both halves of the exchange in one vector instruction, no LDS round trip - a
+// ds_bpermute per step stood here, ~120 cycles of latency each in the middle of every layer's epilogue.  With both operands
+// the same register, lanes l and l ^ 32 (l ^ 16) end up holding the pair (x[l & ~32], x[l | 32]).)
+__device__ __forceinline__ void swap32(uint32_t x, uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ void swap16(uint32_t x, uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ float col_max(float m) {  // m >= 0: the bit patterns order as unsigned integers
+    uint32_t a, b;
+    swap32(__float_as_uint(m), a, b);
+    uint32_t u = a > b ? a : b;
+    if constexpr (NG == 4) {
+        swap16(u, a, b);
+        u = a > b ? a : b;
+    }
+    return __uint_as_float(u);
+}
+// sum over the lane groups of a sample column (every lane group ends with it)
+__device__ __forceinline__ float col_sum(float v) {
+    uint32_t a, b;
+    swap32(__float_as_uint(v), a, b);
+    v = __uint_as_float(a) + __uint_as_float(b);
+    if constexpr (NG == 4) {
+        swap16(__float_as_uint(v), a, b);
+        v = __uint_as_float(a) + __uint_as_float(b);
+    }
+    return v;
 }
 // maximum over the 16 lanes of a DPP row (every lane ends with it); bit patterns of non-negative floats order as integers
 __device__ __forceinline__ uint32_t row_umax(uint32_t v) {
@@ -767,15 +812,15 @@ enum {
 };
 template <int NT>
 __device__ __forceinline__ float lane_amax(const accv (&acc)[NT]) {
-    float m = 0.f;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};  // four running maxima: one chain of NT * ACCR dependent v_max3 otherwise
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < ACCR; ++e) {
             const float x = acc[t][e];
-            m = fmaxf(m, fabsf(x));
+            m[e & 3] = fmaxf(m[e & 3], fabsf(x));
         }
-    return m;
+    return fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
 }
 // value at position i of quad block qb of a vector held as accumulator tiles
 #define AQ(acc, qb, i) (acc)[(qb) / ACCQ][4 * ((qb) % ACCQ) + (i)]
@@ -846,19 +891,20 @@ __device__ __forceinline__ void relu(accv (&acc)[NT]) {
 // backward pass alike.)
 template <int NP, int KS, int KB>
 __device__ __forceinline__ void gate_words(const BFrag<NP> (&b)[KB], Gate& g) {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < MW; ++i) g.w[i] = 0u;
-    const u16x2 one = {1, 1};
+    uint32_t one = 0x00010001u;
+    asm volatile("" : "+v"(one));  // (in a register: the packed minimum takes it as an operand)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const u32x4 h = __builtin_bit_cast(u32x4, b[ks].p[0]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t hq = h[q];
-            const u16x2 m = __builtin_elementwise_min(__builtin_bit_cast(u16x2, hq), one);
-            g.w[(4 * ks + q) >> 4] |= __builtin_bit_cast(uint32_t, m) << ((4 * ks + q) & 15);
+            uint32_t m;  // (hipcc expands a vector min of two unsigned shorts into compares and selects: five instructions)
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(hq), "v"(one));
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(g.w[(4 * ks + q) >> 4]) : "v"(m), "n"((4 * ks + q) & 15));
         }
     }
 }
@@ -1104,8 +1150,7 @@ __device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], co
         }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        dm[i] += __shfl_xor(dm[i], 32, 64);
-        if constexpr (NG == 4) dm[i] += __shfl_xor(dm[i], 16, 64);
+        dm[i] = col_sum(dm[i]);
     }
 }
 // gate, T-layout store and next B operand of a 256-wide hidden vector (backward-direction sweeps and the tangent sweep)
@@ -1512,8 +1557,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sd += AQ(acc, qb, i) * wv[i];
             }
-            sd += __shfl_xor(sd, 32, 64);
-            if constexpr (NG == 4) sd += __shfl_xor(sd, 16, 64);
+            sd = col_sum(sd);
             if (T.live && T.g == 0) a.sdot[T.row] = sd;
         }
     }
@@ -1851,11 +1895,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         const int o = f * 16 + (((q >> 1) ^ ((f >> 3) & 1)) << 3) + (q & 1) * 4;
         if constexpr (NP == 2) {
             const float s = pow2f(ex);
-            uint2 hv, lv;
-            split2_pair(v[0], v[1], s, hv.x, lv.x);
-            split2_pair(v[2], v[3], s, hv.y, lv.y);
-            *reinterpret_cast<uint2*>(plane0 + o) = hv;
-            *reinterpret_cast<uint2*>(plane0 + pstride + o) = lv;
+            const float x4[4] = {v[0], v[1], v[2], v[3]};
+            uint32_t h2[2], l2[2];
+            split2_pairs<2>(x4, s, h2, l2);
+            *reinterpret_cast<uint2*>(plane0 + o) = make_uint2(h2[0], h2[1]);
+            *reinterpret_cast<uint2*>(plane0 + pstride + o) = make_uint2(l2[0], l2[1]);
         } else {
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 hv, mv, lv;
