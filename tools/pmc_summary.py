@@ -25,6 +25,7 @@ def per_kernel(path, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+taken_on = sys.argv[3] if len(sys.argv) > 3 else None
 out = {}
 for k in fetch:
     if "gemm" not in k and "chain" not in k:
@@ -46,4 +47,5 @@ out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate
                 "--no-cpu-baseline --no-inference` (global batch 4096, N=128); averages over all launches of the kernel; "
                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B; the doubled figure "
                 "matches the algorithmic A-operand bytes of the LDS-DMA loads); WRITE_SIZE as is (16-B-per-lane stores).")
+out["_taken_on"] = taken_on  # box / date / workload size of the two passes (tools/final_measure.sh)
 print(json.dumps(out, indent=1))
