@@ -1213,6 +1213,12 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
     R.start(a.pack, lds, fwd_chunk0<NP>(F_COUNT), wid, lane, 0);
     RunMax<10> RM;  // activation slots 0..9
     RM.clear();
+#ifdef PN_TRACE_CHAIN  // shader clock (s_memtime) against the 100 MHz constant clock (s_memrealtime) over the whole kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_chain_trace[60] = __builtin_amdgcn_s_memtime();
+        g_chain_trace[61] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // NP = 2: the weight exponents of this direction, one per lane, fetched once (a load per layer inside the tile loop
     // brought a vmcnt(0) in front of every GEMM; the other waves covered it, the timings did not move)
     int wtab = 0;
@@ -1352,6 +1358,12 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         TR(24);
     }
     R.drain();
+#ifdef PN_TRACE_CHAIN
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_chain_trace[62] = __builtin_amdgcn_s_memtime();
+        g_chain_trace[63] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if constexpr (NP == 2) {
         RM.flush(a.amax ? a.amax + AM_ACT0 : nullptr, lane, wid, lds);
         if (a.amax && blockIdx.x == 0 && tid == 0) a.amax[AM_ENC] = 0x3f800000u;  // |encoding| <= 1

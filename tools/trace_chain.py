@@ -7,7 +7,7 @@ from pano_nerf_amd import _lib
 import tools.check_chain as cc
 
 planes = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-cc.run(4096 * 128, 128, planes, reps=3)
+cc.run(4096 * 128, 128, planes, reps=int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 lib = _lib.load()
 buf = (ctypes.c_uint64 * 64)()
 lib.pn_chain_trace_read.argtypes = [ctypes.c_void_p]
@@ -32,3 +32,6 @@ for i in range(16):
 n = max(t[59], 1)
 print(f"ring acquires of wave 0 / workgroup 0 over the kernel: {t[59]}; mean cycles waiting for own LDS reads {t[56]/n:.0f}, "
       f"for the chunk's DMA {t[57]/n:.0f}, at the barrier {t[58]/n:.0f} (each stamp costs a scalar-memory round trip)")
+if t[63] > t[61]:
+    print(f"in-kernel shader clock of workgroup 0 over the last forward launch: {(t[62] - t[60]) / (t[63] - t[61]) * 100:.0f} MHz "
+          f"({t[62] - t[60]} shader cycles in {(t[63] - t[61]) / 100:.1f} us)")
