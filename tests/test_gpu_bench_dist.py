@@ -30,6 +30,18 @@ def test_two_rank_bench_flow(graph):
     assert out["roofline"]["bound"] in ("mfma", "hbm") and 0 < out["roofline"]["frac"] < 1
     assert out["roofline"]["kernel"].startswith("k_chain_")
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    # the audit record of the data-parallel step: both ranks took part, each with its shard and its own loss, and the
+    # gradient block is the same on both after the all-reduce
+    audit = out["config"]["data_parallel_audit"]
+    assert audit["rays_per_rank"] == [128, 128] and len(audit["last_loss_per_rank"]) == 2
+    assert audit["last_loss_per_rank"][0] != audit["last_loss_per_rank"][1]
+    assert audit["allreduced_grad_l2"] > 0 and audit["allreduced_grad_l2_spread_over_ranks"] == 0.0
+    if graph == "on":  # the captured step was checked against an eager step on the same batch before it was timed
+        assert out["config"]["launch"] == "hip-graph replay"
+        assert out["config"]["replay_check"]["ok_all_ranks"] is True
+        assert out["config"]["replay_check"]["max_grad_diff_over_max_grad"] <= 1e-6
+    else:
+        assert out["config"]["launch"] == "eager" and out["config"]["replay_check"] is None
 
 
 def test_two_rank_render_matches_single_rank():
