@@ -294,7 +294,7 @@ int pn_env_origin_backward(int64_t B, int rows_per_ray, const float* d_mean, con
 
 /* ---- tone-mapped loss (utils/surface_rendering.py:319-344, systems/panonerf_system.py:17,44-67,
  * systems/mipnerf_system.py:24,37-45).  Per-ray partials are reduced in-kernel; `loss_terms`
- * receives [mse_coarse, mse_fine, mse_surface, chrom, mask_sum]; d_* receive the gradients of
+ * receives [mse_coarse, mse_fine, mse_surface, chrom, mask_sum, total]; d_* receive the gradients of
  *   total = cw*mse_coarse + mse_fine + sw*mse_surface + chw*chrom     (ort term added by caller).
  * rgb_surface / albedo may be null (terms skipped).  work: >= 8 + 8*ceil(B/256) floats. */
 int pn_tonemap_loss(int64_t B, const float* rgb_gt_hdr, const float* lossmult, const float* rgb_coarse,

@@ -2224,6 +2224,47 @@ struct WgJob {
 static const int kCfgM[5] = {256, 256, 128, 32, 32};
 static const int kCfgN[5] = {256, 96, 288, 256, 128};
 
+// Slab reduction of one job in ONE launch: dst[r][c] += sum over the nb slabs of their [rows x cols] part (leading dimension
+// src_ld), and dbias[i] += sum of the slabs' row sums (at slab offset bias_off), in a fixed order (64 elements per workgroup,
+// four partial sums each, eight loads in flight): 31 reduction launches per training step were 16 % of its launches at the
+// 512-ray share.
+__global__ __launch_bounds__(256) void k_reduce_job(const float* slabs, int64_t nb, int64_t stride, int rows, int cols, int src_ld,
+                                                     float* dst, int ldd, int64_t bias_off, float* dbias) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx, nw = rows * cols, n = nw + (dbias ? rows : 0);
+    float acc = 0.f;
+    float* d = nullptr;
+    if (e < n) {
+        const float* p;
+        if (e < nw) {
+            const int r = e / cols, c = e - r * cols;
+            p = slabs + (int64_t)r * src_ld + c;
+            d = dst + (int64_t)r * ldd + c;
+        } else {
+            p = slabs + bias_off + (e - nw);
+            d = dbias + (e - nw);
+        }
+        int64_t b = ty;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+        for (; b + 28 < nb; b += 32) {
+            a0 += p[b * stride];
+            a1 += p[(b + 4) * stride];
+            a2 += p[(b + 8) * stride];
+            a3 += p[(b + 12) * stride];
+            a4 += p[(b + 16) * stride];
+            a5 += p[(b + 20) * stride];
+            a6 += p[(b + 24) * stride];
+            a7 += p[(b + 28) * stride];
+        }
+        for (; b < nb; b += 4) a0 += p[b * stride];
+        acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && e < n) *d += (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
 template <int NP>
 static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipStream_t s) {
     WgArgs a{};
@@ -2265,11 +2306,11 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     }
     }
     PN_CHECK_LAUNCH();
-    float* scratch = work + nsplit * stride;
-    int rc = pn_launch_reduce_rows(work, nsplit, stride, j.rows, j.cols, TNW, j.dst, j.ldd, 1, scratch, s);
-    if (rc != PN_OK) return rc;
-    if (j.dbias) rc = pn_launch_reduce_rows(work + (int64_t)TMW * TNW, nsplit, stride, 1, j.rows, TMW, j.dbias, j.rows, 1, scratch, s);
-    return rc;
+    const int n = j.rows * j.cols + (j.dbias ? j.rows : 0);
+    hipLaunchKernelGGL(k_reduce_job, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, work, nsplit, stride, j.rows, j.cols, TNW,
+                       j.dst, j.ldd, (int64_t)TMW * TNW, j.dbias);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
 }
 
 extern "C" {

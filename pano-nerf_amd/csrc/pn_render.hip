@@ -910,7 +910,8 @@ __global__ __launch_bounds__(256) void k_loss_partial(LossArgs a, float* partial
     if (threadIdx.x < 5) partial[blockIdx.x * 8 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void k_loss_final(int nblocks, int64_t B, const float* partial, float* terms) {
+__global__ __launch_bounds__(256) void k_loss_final(int nblocks, int64_t B, const float* partial, float* terms, float cw, float sw,
+                                                     float chw, int has_surface, int has_albedo) {
     __shared__ float red[4][8];
     float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < nblocks; i += 256)
@@ -929,7 +930,12 @@ __global__ __launch_bounds__(256) void k_loss_final(int nblocks, int64_t B, cons
         terms[2] = t[2] / t[4];
         terms[3] = t[3] / (float)(B * 3);
         terms[4] = t[4];
-        terms[5] = terms[6] = terms[7] = 0.f;
+        // the weighted total, in the order the caller used to form it with four small torch kernels (same fp32 operations)
+        float total = cw * terms[0] + terms[1];
+        if (has_surface) total = total + sw * terms[2];
+        if (has_albedo) total = total + chw * terms[3];
+        terms[5] = total;
+        terms[6] = terms[7] = 0.f;
     }
 }
 
@@ -1267,7 +1273,8 @@ int pn_tonemap_loss(int64_t B, const float* rgb_gt_hdr, const float* lossmult, c
     int nb = (int)nblk(B, 256);
     hipLaunchKernelGGL(k_loss_partial, dim3(nb), dim3(256), 0, ST(stream), a, work);
     PN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, ST(stream), nb, B, work, loss_terms);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, ST(stream), nb, B, work, loss_terms, coarse_w, surface_w, chrom_w,
+                       rgb_surface != nullptr, albedo != nullptr);
     PN_CHECK_LAUNCH();
     if (d_coarse && d_fine) {
         hipLaunchKernelGGL(k_loss_grad, dim3(nb), dim3(256), 0, ST(stream), a, loss_terms, coarse_w, surface_w, chrom_w,

@@ -38,11 +38,7 @@ class _ToneLossFn(torch.autograd.Function):
                       _lib.ptr(rgb_s), _lib.ptr(albedo_in), float(cw), float(sw), float(chw), terms.data_ptr(),
                       grads[0].data_ptr(), grads[1].data_ptr(), _lib.ptr(g_s), _lib.ptr(g_a), work.data_ptr(),
                       torch.cuda.current_stream(dev).cuda_stream)
-        total = cw * terms[0] + terms[1]
-        if rgb_s is not None:
-            total = total + sw * terms[2]
-        if albedo_in is not None:
-            total = total + chw * terms[3]
+        total = terms[5].clone()  # cw * terms[0] + terms[1] (+ sw * terms[2]) (+ chw * terms[3]), formed by the kernel
         ctx.grads = (grads[0], grads[1], g_s, g_a)
         ctx.mark_non_differentiable(terms)
         return total, terms
@@ -51,8 +47,9 @@ class _ToneLossFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_total, _g_terms):
         gc, gf, gs, ga = ctx.grads
-        s = lambda g: None if g is None else g * g_total
-        return None, None, None, s(gc), s(gf), s(gs), s(ga)
+        live = [g for g in (gc, gf, gs, ga) if g is not None]
+        torch._foreach_mul_(live, g_total)  # ONE launch for the (up to) four [B,3] gradients; they are this call's own buffers
+        return None, None, None, gc, gf, gs, ga
 
 
 def pano_loss(outputs, lossmult, rgbs, hparams=DEFAULT_LOSS, surface=True):

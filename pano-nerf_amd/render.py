@@ -322,12 +322,15 @@ class _RenderFn(torch.autograd.Function):
             st = torch.cuda.current_stream(dev).cuda_stream
             flat_grad = torch.zeros(params.numel(), dtype=torch.float32, device=dev)  # outlives this call (.grad views)
             pending = []  # (evaluation, its workspace, ran the tangent sweep): weight gradients batched into the last call
-            d_dist1 = gz(g_dist1, B).clone()
+            d_dist1 = gz(g_dist1, B).clone() if g_dist1 is not None else z(B)  # (accumulated into below: a private buffer)
             d_normal = gz(g_normal, B, 3) if cfg.normals else None
             d_albedo = None
             if cfg.surf:
                 D, Ne = env_d.shape[0], cfg.num_env_samples
-                d_dif = gz(g_surface, B, 3) + gz(g_diffuse, B, 3)
+                if g_surface is not None and g_diffuse is not None:
+                    d_dif = _f32(g_surface) + _f32(g_diffuse)
+                else:  # (the training loss reads surface_rgb only: no add)
+                    d_dif = gz(g_surface if g_surface is not None else g_diffuse, B, 3)
                 d_shd = gz(g_shading, B, 3)
                 d_env, d_alb_s, d_nrm_s = z(B, D, 3), z(B, 3), z(B, 3)
                 _lib.call("pn_surface_backward", B, D, env_rgb.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
@@ -461,9 +464,15 @@ class _RenderBase(torch.nn.Module):
         radii, near, far = _f32(rays.radii).reshape(-1), _f32(rays.near).reshape(-1), _f32(rays.far).reshape(-1)
         dev = o.device
         if env_rays is not None and surf:
-            env = [_f32(env_rays.directions.to(dev)), _f32(env_rays.radii.to(dev)).reshape(-1),
-                   _f32(env_rays.near.to(dev)).reshape(-1), _f32(env_rays.far.to(dev)).reshape(-1),
-                   _f32(env_rays.lossmult.to(dev)).reshape(-1)]
+            # the caller's env rays are the same fp16 tensors every step (systems/base_system.py:57-79): their fp32 device
+            # copies are cached on the tensors' identity and version (five conversion launches per step otherwise)
+            src = (env_rays.directions, env_rays.radii, env_rays.near, env_rays.far, env_rays.lossmult)
+            key = tuple((x.data_ptr(), x._version, x.dtype, tuple(x.shape)) for x in src) + (str(dev),)
+            if getattr(self, "_env_key", None) != key:
+                self._env_f32 = [_f32(src[0].to(dev))] + [_f32(x.to(dev)).reshape(-1) for x in src[1:]]
+                self._env_key = key
+                self._env_src = src  # keeps the sources alive: their addresses cannot be handed to other tensors meanwhile
+            env = self._env_f32
         else:
             env = [torch.zeros(1, 3, device=dev)] + [torch.zeros(1, device=dev)] * 4
         t_rand, u_rand, env_rand = self._noise(randomized, o.shape[0], dev, surf)
