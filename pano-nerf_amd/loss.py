@@ -48,8 +48,8 @@ class _ToneLossFn(torch.autograd.Function):
     def backward(ctx, g_total, _g_terms):
         gc, gf, gs, ga = ctx.grads
         live = [g for g in (gc, gf, gs, ga) if g is not None]
-        torch._foreach_mul_(live, g_total)  # ONE launch for the (up to) four [B,3] gradients; they are this call's own buffers
-        return None, None, None, gc, gf, gs, ga
+        out = iter(torch._foreach_mul(live, g_total))  # ONE launch for the (up to) four [B,3] gradients
+        return (None, None, None) + tuple(None if g is None else next(out) for g in (gc, gf, gs, ga))
 
 
 def pano_loss(outputs, lossmult, rgbs, hparams=DEFAULT_LOSS, surface=True):
