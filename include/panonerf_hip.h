@@ -96,10 +96,10 @@ int pn_sample_pano_rays(int64_t B, int n_cam, int H, int W, const int64_t* idx, 
                         float* lossmult, float* near_out, float* far_out, float* noise_var, float* rgb_out, void* stream);
 
 /* ---- sampling ----------------------------------------------------------------------
- * sample_along_rays (models/mip.py:113-151, disparity = False) + cast_rays (67-89) +
+ * sample_along_rays (models/mip.py:113-151; disparity != 0: positions linear in inverse depth, :134-136) + cast_rays (67-89) +
  * conical_frustum_to_gaussian (36-64, stable) + lift_gaussian (8-22, diagonal).
  * t_rand: [B,S] uniforms or null (deterministic). */
-int pn_sample_coarse(int64_t B, int N, const float* origins, const float* directions, const float* radii,
+int pn_sample_coarse(int64_t B, int N, int disparity, const float* origins, const float* directions, const float* radii,
                      const float* near_, const float* far_, const float* t_rand, float* t_out, float* mean,
                      float* cov, void* stream);
 /* resample_along_rays (models/mip.py:304-352, stop_grad branch) + sorted_piecewise_constant_pdf

@@ -116,11 +116,14 @@ def _jitter(t, t_rand):
     return lower + (upper - lower) * t_rand
 
 
-def sample_along_rays(origins, directions, radii, num_samples, near, far, t_rand=None):
-    """Stratified coarse sampling (disparity=False).  models/mip.py:113-151.
+def sample_along_rays(origins, directions, radii, num_samples, near, far, t_rand=None, disparity=False):
+    """Stratified coarse sampling, linear in depth or (disparity) in inverse depth.  models/mip.py:113-151.
     ``t_rand`` [B, S] uniform noise (``None`` = deterministic)."""
     lin = torch.linspace(0.0, 1.0, num_samples + 1)
-    t = near + (far - near) * lin
+    if disparity:
+        t = 1.0 / (1.0 / near * (1.0 - lin) + 1.0 / far * lin)  # models/mip.py:134-136
+    else:
+        t = near + (far - near) * lin
     if t_rand is not None:
         t = _jitter(t, t_rand)
     else:
@@ -371,7 +374,7 @@ def hdr_to_ldr(color, gamma=2.2, quantize=False):
 # --------------------------------------------------------------------- full forwards
 def pano_forward(p, rays, env_rays, *, num_samples, white_bkgd=False, enable_surf=True,
                  use_ort_loss=True, noise=None, num_env_samples=10, resample_padding=0.01,
-                 rgb_padding=0.0, density_bias=-1.0, normals_mode="fast"):
+                 rgb_padding=0.0, density_bias=-1.0, normals_mode="fast", disparity=False):
     """PanoMipNeRF.forward, models/pano_mip_nerf.py:197-363.
     ``noise`` = None (deterministic) or dict(t_rand [B,S], u_rand [B,S], env_rand [1,Ne+1])."""
     kw = dict(rgb_padding=rgb_padding, density_bias=density_bias)
@@ -381,7 +384,7 @@ def pano_forward(p, rays, env_rays, *, num_samples, white_bkgd=False, enable_sur
     for level in range(2):
         if level == 0:
             t, (mean, cov) = sample_along_rays(rays.origins, rays.directions, rays.radii, num_samples,
-                                               rays.near, rays.far, None if noise is None else noise["t_rand"])
+                                               rays.near, rays.far, None if noise is None else noise["t_rand"], disparity)
         else:
             t, (mean, cov) = resample_along_rays(rays.origins, rays.directions, rays.radii, t, w.detach().clone(),
                                                  resample_padding, None if noise is None else noise["u_rand"])
@@ -411,7 +414,7 @@ def pano_forward(p, rays, env_rays, *, num_samples, white_bkgd=False, enable_sur
 
 
 def mip_forward(p, rays, *, num_samples, white_bkgd=False, use_ort_loss=False, noise=None,
-                resample_padding=0.01, rgb_padding=0.0, density_bias=-1.0, normals_mode="fast"):
+                resample_padding=0.01, rgb_padding=0.0, density_bias=-1.0, normals_mode="fast", disparity=False):
     """MipNeRF.forward, models/mip_nerf.py:170-283."""
     kw = dict(rgb_padding=rgb_padding, density_bias=density_bias)
     ret = []
@@ -419,7 +422,7 @@ def mip_forward(p, rays, *, num_samples, white_bkgd=False, use_ort_loss=False, n
     for level in range(2):
         if level == 0:
             t, (mean, cov) = sample_along_rays(rays.origins, rays.directions, rays.radii, num_samples,
-                                               rays.near, rays.far, None if noise is None else noise["t_rand"])
+                                               rays.near, rays.far, None if noise is None else noise["t_rand"], disparity)
         else:
             t, (mean, cov) = resample_along_rays(rays.origins, rays.directions, rays.radii, t, w.detach().clone(),
                                                  resample_padding, None if noise is None else noise["u_rand"])

@@ -25,7 +25,7 @@ SIGNATURES = {
     "pn_lit_rays": ("i", "idddpp"),
     "pn_gather_rays": ("i", "llpppp"),
     "pn_sample_pano_rays": ("i", "liiippffp" + "p" * 9 + "p"),
-    "pn_sample_coarse": ("i", "li" + "p" * 9 + "p"),
+    "pn_sample_coarse": ("i", "lii" + "p" * 9 + "p"),
     "pn_resample": ("i", "lippfp" + "p" * 6 + "p"),
     "pn_sample_env": ("i", "lii" + "p" * 11 + "p"),
     "pn_ipe_encode": ("i", "lpppp"),

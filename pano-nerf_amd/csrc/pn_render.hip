@@ -185,11 +185,18 @@ __global__ void k_lit_rays(int D, double radius, double near_, double far_, uint
 }
 
 // --------------------------------------------------------------------------- coarse sampling
-__device__ __forceinline__ float coarse_t(float nr, float fr, int S, int s, const float* rnd_row) {
-    float t = nr + (fr - nr) * linspace_at(0.f, 1.f, S, s);
+// the s-th of S sample positions between near and far: linear in depth, or - disparity - linear in inverse depth
+// (models/mip.py:134-138: 1 / (1 / near * (1 - x) + 1 / far * x), in that order of operations)
+__device__ __forceinline__ float base_t(float nr, float fr, int S, int s, bool disparity) {
+    const float x = linspace_at(0.f, 1.f, S, s);
+    if (disparity) return 1.f / (1.f / nr * (1.f - x) + 1.f / fr * x);
+    return nr + (fr - nr) * x;
+}
+__device__ __forceinline__ float coarse_t(float nr, float fr, int S, int s, const float* rnd_row, bool disparity = false) {
+    float t = base_t(nr, fr, S, s, disparity);
     if (rnd_row) {
-        float tm1 = (s > 0) ? nr + (fr - nr) * linspace_at(0.f, 1.f, S, s - 1) : t;
-        float tp1 = (s < S - 1) ? nr + (fr - nr) * linspace_at(0.f, 1.f, S, s + 1) : t;
+        float tm1 = (s > 0) ? base_t(nr, fr, S, s - 1, disparity) : t;
+        float tp1 = (s < S - 1) ? base_t(nr, fr, S, s + 1, disparity) : t;
         float lower = (s > 0) ? 0.5f * (t + tm1) : t;
         float upper = (s < S - 1) ? 0.5f * (tp1 + t) : t;
         t = lower + (upper - lower) * rnd_row[s];
@@ -197,7 +204,7 @@ __device__ __forceinline__ float coarse_t(float nr, float fr, int S, int s, cons
     return t;
 }
 
-__global__ void k_sample_coarse(int64_t B, int N, const float* origins, const float* directions, const float* radii,
+__global__ void k_sample_coarse(int64_t B, int N, int disparity, const float* origins, const float* directions, const float* radii,
                                 const float* near_, const float* far_, const float* t_rand, float* t_out, float* mean,
                                 float* cov) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,7 +214,7 @@ __global__ void k_sample_coarse(int64_t B, int N, const float* origins, const fl
     const int S = N + 1;
     float nr = near_[b], fr = far_[b];
     const float* rr = t_rand ? t_rand + b * S : nullptr;
-    float t0 = coarse_t(nr, fr, S, n, rr), t1 = coarse_t(nr, fr, S, n + 1, rr);
+    float t0 = coarse_t(nr, fr, S, n, rr, disparity != 0), t1 = coarse_t(nr, fr, S, n + 1, rr, disparity != 0);
     t_out[b * S + n] = t0;
     if (n == N - 1) t_out[b * S + N] = t1;
     float o[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
@@ -1108,13 +1115,13 @@ int pn_lit_rays(int D, double radius, double near_, double far_, uint16_t* out_h
     return PN_OK;
 }
 
-int pn_sample_coarse(int64_t B, int N, const float* origins, const float* directions, const float* radii,
+int pn_sample_coarse(int64_t B, int N, int disparity, const float* origins, const float* directions, const float* radii,
                      const float* near_, const float* far_, const float* t_rand, float* t_out, float* mean, float* cov,
                      void* stream) {
     if (B <= 0 || N <= 0) return PN_ERR_BAD_SHAPE;
     if (N > PN_MAX_SAMPLES) return PN_ERR_UNSUPPORTED;
     if (!origins || !directions || !radii || !near_ || !far_ || !t_out || !mean || !cov) return PN_ERR_NULL;
-    hipLaunchKernelGGL(k_sample_coarse, dim3(nblk(B * N, 256)), dim3(256), 0, ST(stream), B, N, origins, directions,
+    hipLaunchKernelGGL(k_sample_coarse, dim3(nblk(B * N, 256)), dim3(256), 0, ST(stream), B, N, disparity, origins, directions,
                        radii, near_, far_, t_rand, t_out, mean, cov);
     PN_CHECK_LAUNCH();
     return PN_OK;

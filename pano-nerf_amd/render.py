@@ -211,7 +211,7 @@ class _RenderFn(torch.autograd.Function):
             # ---- level 0: stratified samples
             e0 = _Eval(M, N, vd, nc, dev, planes, keep)
             e0.t = e(B, S)
-            _lib.call("pn_sample_coarse", B, N, o.data_ptr(), d.data_ptr(), radii.data_ptr(), near.data_ptr(),
+            _lib.call("pn_sample_coarse", B, N, int(cfg.disparity), o.data_ptr(), d.data_ptr(), radii.data_ptr(), near.data_ptr(),
                       far.data_ptr(), _lib.ptr(t_rand), e0.t.data_ptr(), e0.mean.data_ptr(), e0.cov.data_ptr(), st)
             _mlp_forward(e0, params, wpack, st)
             comp0, dist0, _, w0 = _composite_forward(e0, B, N, cfg, cfg.white_bkgd, d, B, st)
@@ -413,7 +413,6 @@ class _RenderBase(torch.nn.Module):
         if num_levels != 2: unsupported.append("num_levels != 2")
         if not stop_resample_grad: unsupported.append("stop_resample_grad=False")
         if not use_viewdirs: unsupported.append("use_viewdirs=False")
-        if disparity: unsupported.append("disparity=True")
         if disable_integration: unsupported.append("disable_integration=True")
         if density_noise and density_noise > 0: unsupported.append("density_noise > 0")
         if (min_deg_point, max_deg_point, deg_view) != (0, 16, 4): unsupported.append("encoding degrees != (0,16,4)")
@@ -424,6 +423,7 @@ class _RenderBase(torch.nn.Module):
                                       + ", ".join(unsupported))
         self.num_samples, self.num_levels = int(num_samples), int(num_levels)
         self.resample_padding = float(resample_padding)
+        self.disparity = bool(disparity)  # coarse samples linear in inverse depth (models/mip.py:134-136)
         self.density_bias, self.rgb_padding = float(density_bias), float(rgb_padding)
         self.num_env_samples = int(num_env_samples)
         self.mlp = RadianceMLP(mlp_net_depth, mlp_net_width, mlp_net_depth_condition, mlp_net_width_condition,
@@ -477,7 +477,7 @@ class _RenderBase(torch.nn.Module):
             env = [torch.zeros(1, 3, device=dev)] + [torch.zeros(1, device=dev)] * 4
         t_rand, u_rand, env_rand = self._noise(randomized, o.shape[0], dev, surf)
         cfg = _Cfg(num_samples=self.num_samples, nc=self._NC, density_bias=self.density_bias,
-                   rgb_padding=self.rgb_padding, resample_padding=self.resample_padding,
+                   rgb_padding=self.rgb_padding, resample_padding=self.resample_padding, disparity=self.disparity,
                    white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
                    num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads, planes=_planes_of(self.mlp_mode),
                    batch_wgrad=self.batch_weight_grads,

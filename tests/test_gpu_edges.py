@@ -82,9 +82,9 @@ def test_refused_arguments():
     h = _lib.load()
     x = torch.zeros(64, device=dev())
     p = x.data_ptr()
-    assert h.pn_sample_coarse(0, 8, p, p, p, p, p, None, p, p, p, None) == -1          # empty batch
-    assert h.pn_sample_coarse(4, 513, p, p, p, p, p, None, p, p, p, None) == -2        # beyond PN_MAX_SAMPLES
-    assert h.pn_sample_coarse(4, 8, None, p, p, p, p, None, p, p, p, None) == -3       # null pointer
+    assert h.pn_sample_coarse(0, 8, 0, p, p, p, p, p, None, p, p, p, None) == -1          # empty batch
+    assert h.pn_sample_coarse(4, 513, 0, p, p, p, p, p, None, p, p, p, None) == -2        # beyond PN_MAX_SAMPLES
+    assert h.pn_sample_coarse(4, 8, 0, None, p, p, p, p, None, p, p, p, None) == -3       # null pointer
     assert h.pn_composite_forward(4, 8, 3, -1.0, 0.0, 0, p, p, p, p, 4, p, p, p, p, None) == -2  # density channels
     assert h.pn_resample(4, 1, p, p, 0.01, None, p, p, p, p, p, p, None) == -1
     with pytest.raises(RuntimeError, match="bad shape"):

@@ -76,7 +76,7 @@ def test_sampling(lib, golden, case):
     rad, nr, fr = G(g["ray_radii"]).view(-1), G(g["ray_near"]).view(-1), G(g["ray_far"]).view(-1)
     for rnd, kt, km, kc in ((None, "t_det", "mean_det", "cov_det"), (G(g["t_rand"]), "t_rnd", "mean_rnd", "cov_rnd")):
         t, m, c = E(B, S), E(B * N, 3), E(B * N, 3)
-        lib.call("pn_sample_coarse", B, N, o.data_ptr(), d.data_ptr(), rad.data_ptr(), nr.data_ptr(), fr.data_ptr(),
+        lib.call("pn_sample_coarse", B, N, 0, o.data_ptr(), d.data_ptr(), rad.data_ptr(), nr.data_ptr(), fr.data_ptr(),
                  lib.ptr(rnd), t.data_ptr(), m.data_ptr(), c.data_ptr(), st())
         assert rel_err(C(t), g[kt]) < 1e-6, kt
         assert rel_err(C(m).view(B, N, 3), g[km]) < 1e-6, km
@@ -357,3 +357,47 @@ def test_adam_matches_torch(lib):
         opt.step(flat_grad=gr.to(dev()))
     assert rel_err(C(m.mlp.flat_params()), ref_p.detach()) < 1e-6
     assert m.mlp.is_flat()
+
+
+def test_disparity_sampling_and_models(lib, golden):
+    """`disparity=True` (models/mip.py:134-136): pn_sample_coarse with the flag, and both drop-in models constructed with
+    disparity=True, against vectors captured from the reference (tests/golden/make_disparity_golden.py)."""
+    import pano_nerf_amd as pn
+    from oracle import pano_oracle as orc
+    from conftest import assert_close
+    g = golden("disparity_B16_N32")
+    B, S = g["t_det"].shape
+    N = S - 1
+    o, d = G(g["ray_origins"]), G(g["ray_directions"])
+    rad, nr, fr = G(g["ray_radii"]).view(-1), G(g["ray_near"]).view(-1), G(g["ray_far"]).view(-1)
+    for rnd, kt, km, kc in ((None, "t_det", "mean_det", "cov_det"), (G(g["t_rand"]), "t_rnd", "mean_rnd", "cov_rnd")):
+        t, m, c = E(B, S), E(B * N, 3), E(B * N, 3)
+        lib.call("pn_sample_coarse", B, N, 1, o.data_ptr(), d.data_ptr(), rad.data_ptr(), nr.data_ptr(), fr.data_ptr(),
+                 lib.ptr(rnd), t.data_ptr(), m.data_ptr(), c.data_ptr(), st())
+        assert rel_err(C(t), g[kt]) < 1e-6, kt
+        assert rel_err(C(m).view(B, N, 3), g[km]) < 1e-6, km
+        assert rel_err(C(c).view(B, N, 3), g[kc]) < 1e-5, kc
+    rays = pn.Rays(*[G(g["ray_" + k]) for k in pn.Rays._fields])
+    env = pn.generate_lit_rays(10, float(orc.synthetic_scene(8, 16, 3, seed=4)[2]))
+    names = ("comp_rgb", "distance", "ort_loss", "normal", "albedo", "roughness", "surface_rgb", "diffuse", "shading")
+    model = pn.PanoMipNeRF(num_samples=N, disparity=True, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=5)
+    model.mlp.load_state_dict(orc.init_params(4, 5))
+    model = model.to(o.device)
+    with torch.no_grad():
+        outs = model(rays=rays, env_rays=env, randomized=False, white_bkgd=False, enable_surf=True, use_ort_loss=True)
+    for lvl, tup in enumerate(outs):
+        for n, v in zip(names, tup):
+            if v is None:
+                continue
+            if n in ("normal", "surface_rgb", "diffuse", "shading", "ort_loss"):  # density-gradient outputs: SURVEY 7
+                assert rel_err(C(v), g[f"pano/l{lvl}/{n}"]) < 5e-2, (lvl, n)
+            else:
+                assert_close(C(v).numpy(), g[f"pano/l{lvl}/{n}"], f"disparity/pano/l{lvl}/{n}")
+    mip = pn.MipNeRF(num_samples=N, disparity=True, rgb_activation="softplus", rgb_padding=0, mlp_num_density_channels=1)
+    mip.mlp.load_state_dict(orc.init_params(4, 1))
+    mip = mip.to(o.device)
+    with torch.no_grad():
+        mouts = mip(rays=rays, randomized=False, white_bkgd=False, use_ort_loss=False)
+    for lvl in (0, 1):
+        assert_close(C(mouts[lvl][0]).numpy(), g[f"mip/l{lvl}/comp_rgb"], f"disparity/mip/l{lvl}/comp_rgb")
+        assert_close(C(mouts[lvl][1]).numpy(), g[f"mip/l{lvl}/distance"], f"disparity/mip/l{lvl}/distance")

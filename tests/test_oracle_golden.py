@@ -230,3 +230,26 @@ def test_oracle_full_gradients_match_the_reference(golden, case):
         else:
             assert float(np.median(err)) <= 1e-4 and float(np.mean(err <= 1e-3)) >= 0.99, (k, float(np.median(err)))
     assert o == ref.size
+
+
+def test_oracle_disparity_sampling_and_forward(golden):
+    """`disparity=True` (coarse samples linear in inverse depth, models/mip.py:134-136): the oracle against the reference's
+    sample_along_rays and against the val-mode forward tuples of both models built with disparity=True
+    (tests/golden/make_disparity_golden.py)."""
+    g = golden("disparity_B16_N32")
+    rays = orc.Rays(*[torch.from_numpy(g["ray_" + k]) for k in orc.Rays._fields])
+    N = g["t_det"].shape[1] - 1
+    for t_rand, kt, km, kc in ((None, "t_det", "mean_det", "cov_det"), (torch.from_numpy(g["t_rand"]), "t_rnd", "mean_rnd", "cov_rnd")):
+        t, (m, c) = orc.sample_along_rays(rays.origins, rays.directions, rays.radii, N, rays.near, rays.far, t_rand, disparity=True)
+        assert rel_err(t, g[kt]) < 1e-6 and rel_err(m, g[km]) < 1e-6 and rel_err(c, g[kc]) < 1e-5
+    env = orc.generate_lit_rays(10, float(orc.synthetic_scene(8, 16, 3, seed=4)[2]))
+    with torch.no_grad():
+        outs = orc.pano_forward(orc.init_params(4, 5), rays, env, num_samples=N, disparity=True)
+        mouts = orc.mip_forward(orc.init_params(4, 1), rays, num_samples=N, disparity=True)
+    names = ("comp_rgb", "distance", "ort_loss", "normal", "albedo", "roughness", "surface_rgb", "diffuse", "shading")
+    for lvl, tup in enumerate(outs):
+        for n, v in zip(names, tup):
+            if v is not None:
+                assert rel_err(v, g[f"pano/l{lvl}/{n}"]) < (5e-3 if n in ("normal", "surface_rgb", "diffuse", "shading", "ort_loss") else 1e-5), (lvl, n)
+    for lvl in (0, 1):
+        assert rel_err(mouts[lvl][0], g[f"mip/l{lvl}/comp_rgb"]) < 1e-5 and rel_err(mouts[lvl][1], g[f"mip/l{lvl}/distance"]) < 1e-5
