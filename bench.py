@@ -77,7 +77,7 @@ def cpu_baseline(n_samples, rays_cpu, rgbs_cpu, env_cpu, b_cpu, reps=3):
     t0 = time.perf_counter()
     step(rays, rgbs, "fast")
     t_fast = time.perf_counter() - t0
-    out = {"value": b_cpu / med, "unit": "rays/s", "cores": os.cpu_count(), "threads": torch.get_num_threads(),
+    out = {"value": b_cpu / med, "unit": "rays/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(),
            "kind": "port",
            "sample": f"median of {reps} train steps (fwd+bwd+Adam, faithful vmap(jacrev) normals) after 1 warm-up, each on "
                      f"{b_cpu} rays x {n_samples}+{n_samples} samples of the same synthetic batch, fp32",
