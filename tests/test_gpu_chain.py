@@ -245,3 +245,76 @@ def test_weight_gradients_over_segments_whose_magnitudes_are_1e30_apart(order):
     for k in ORDER:
         e = rel(got[offs[k]:offs[k] + shapes[k]], want[k])
         assert e < 1e-5, (k, e)
+
+
+def _synthetic_eval(lib, M, nc, gen, ray_spread):
+    """One evaluation's T tensors on the GPU with a training step's shape: ReLU activations, half-gated deltas whose
+    magnitude varies from ray to ray (log-normal, sigma = ray_spread e-folds over rays of 128 samples)."""
+    tile = int(lib.pn_chain_tile())
+    Mp = int(lib.pn_pad_rows(M))
+    assert Mp == M
+    d = dev()
+    AM = dict(enc=0, act=1, delta=11, d8b=19, d8d=20, dhv=21, drgb=22)
+    R = lambda f: torch.randn(Mp, f, generator=gen, device=d)
+    ray = torch.exp(ray_spread * torch.randn(Mp // 128, 1, generator=gen, device=d)).repeat_interleave(128, 0)
+    t_of = lambda rows: rows.reshape(Mp // tile, tile, rows.shape[1]).permute(0, 2, 1).contiguous().reshape(-1)
+    enc = R(96).clamp(-1, 1)
+    acts = [torch.relu(R(256) + 0.3) for _ in range(8)] + [R(288), torch.relu(R(128))]
+    delta = [R(256) * ray * (torch.rand(Mp, 256, generator=gen, device=d) > 0.5) for _ in range(8)]
+    d8 = torch.cat([R(256) * ray, R(nc) * ray, torch.zeros(Mp, 32 - nc, device=d)], 1)
+    dhv, drgb = R(128) * ray, torch.cat([R(3) * ray, torch.zeros(Mp, 29, device=d)], 1)
+    amax = torch.zeros(int(lib.pn_chain_amax_slots()), dtype=torch.float32, device=d)
+    amax[AM["enc"]] = enc.abs().max()
+    for i, a in enumerate(acts):
+        amax[AM["act"] + i] = a.abs().max()
+    for i, dl in enumerate(delta):
+        amax[AM["delta"] + i] = dl.abs().max()
+    amax[AM["d8b"]], amax[AM["d8d"]] = d8[:, :256].abs().max(), d8[:, 256:].abs().max()
+    amax[AM["dhv"]], amax[AM["drgb"]] = dhv.abs().max(), drgb.abs().max()
+    bufs = dict(enc_t=t_of(enc), acts_t=torch.cat([t_of(a) for a in acts]), drgb_t=t_of(drgb), dhv_t=t_of(dhv), d8_t=t_of(d8),
+                delta_t=torch.cat([t_of(x) for x in delta]), amax=amax.view(torch.int32))
+    ev = EvalC(M, bufs["enc_t"].data_ptr(), bufs["acts_t"].data_ptr(), bufs["drgb_t"].data_ptr(), bufs["dhv_t"].data_ptr(),
+               bufs["d8_t"].data_ptr(), bufs["delta_t"].data_ptr(), None, None, None, None, bufs["amax"].data_ptr())
+    pairs = {}  # the 256 x 256 sums: (delta rows, input rows)
+    for l in (1, 2, 3, 4, 6, 7):
+        pairs[f"layers.{l}.0.weight"] = (delta[l], acts[l - 1])
+    pairs["extra_layer.weight"] = (d8[:, :256], acts[7])
+    return ev, bufs, pairs
+
+
+@pytest.mark.parametrize("ray_spread", [0.0, 2.0])
+def test_large_weight_gradient_sums_against_fp64_and_an_fp32_gemm(ray_spread):
+    """The 256 x 256 weight-gradient tile (fp16 pairs, three products per fp32 product) on sums over 2^17 samples, against the
+    fp64 product of the same T tensors and next to an fp32 GEMM of the same operands (torch.matmul: the reference's arithmetic,
+    models/pano_mip_nerf.py:95-114 through autograd).  Deltas zero-mean and half gated - the sums cancel to ~sqrt(M) terms, the
+    hard case for a rounding error per term; ray_spread = 2: a few percent of the rays carry most of every sum.
+    Gates: every element within 2e-6 of the tensor's largest, element-wise 1e-4 where |ref| > 1e-3 max, and no worse than the
+    fp32 GEMM's own error.  (A LEAN form - the delta operand as its leading fp16 half only, two products - was measured here in
+    round 3: 13 % faster, 1.9e-4 of the tensor's largest element off, 60 x the fp32 GEMM's error: not shipped,
+    profiles/r03_experiments.txt section 10.)"""
+    from pano_nerf_amd import _lib
+    from pano_nerf_amd.mlp import param_layout
+    lib = _lib.load()
+    nc, M = 5, 1 << 17
+    offs, total = param_layout(nc)
+    gen = torch.Generator(device=dev()).manual_seed(11)
+    ev, bufs, pairs = _synthetic_eval(lib, M, nc, gen, ray_spread)
+    arr = (EvalC * 1)(ev)
+    wfl = int(lib.pn_chain_wgrad_work_floats())
+    work = torch.empty(wfl, dtype=torch.float32, device=dev())
+    lib.pn_chain_wgrad.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int64, ctypes.c_void_p]
+    g = torch.zeros(total, dtype=torch.float32, device=dev())
+    _lib.check(lib.pn_chain_wgrad(1, ctypes.cast(arr, ctypes.c_void_p), nc, 2, g.data_ptr(), work.data_ptr(), wfl, st()),
+               "pn_chain_wgrad")
+    torch.cuda.synchronize()
+    for k, (dl, x) in pairs.items():
+        want = (dl.double().T @ x.double()).reshape(-1)
+        f32 = (dl.T @ x).reshape(-1).double()
+        top = float(want.abs().max())
+        big = want.abs() > 1e-3 * top
+        err = {"ours": (g[offs[k]:offs[k] + 65536].double() - want).abs(), "fp32 gemm": (f32 - want).abs()}
+        row = {n: (float(e.max()) / top, float((e[big] / want[big].abs()).max())) for n, e in err.items()}
+        print(k, {n: "%.2e / %.2e" % v for n, v in row.items()})
+        assert row["ours"][0] < 2e-6 and row["ours"][1] < 1e-4, (k, row)
+        assert row["ours"][0] <= max(row["fp32 gemm"][0], 5e-7), (k, row)
