@@ -288,8 +288,9 @@ def test_large_weight_gradient_sums_against_fp64_and_an_fp32_gemm(ray_spread):
     fp64 product of the same T tensors and next to an fp32 GEMM of the same operands (torch.matmul: the reference's arithmetic,
     models/pano_mip_nerf.py:95-114 through autograd).  Deltas zero-mean and half gated - the sums cancel to ~sqrt(M) terms, the
     hard case for a rounding error per term; ray_spread = 2: a few percent of the rays carry most of every sum.
-    Gates: every element within 2e-6 of the tensor's largest, element-wise 1e-4 where |ref| > 1e-3 max, and no worse than the
-    fp32 GEMM's own error.  (A LEAN form - the delta operand as its leading fp16 half only, two products - was measured here in
+    Gates: every element within 2e-6 of the tensor's largest and no worse than the fp32 GEMM's own error there; element-wise, where
+    |ref| > 1e-3 max, within 1e-4 or the fp32 GEMM's own element-wise error (an fp32 result 1000 x below the tensor's largest element
+    that is a cancelling sum of 2^17 terms is not known to 1e-4 by EITHER arithmetic: measured 1.7e-4 ours, 8.8e-4 the fp32 GEMM).  (A LEAN form - the delta operand as its leading fp16 half only, two products - was measured here in
     round 3: 13 % faster, 1.9e-4 of the tensor's largest element off, 60 x the fp32 GEMM's error: not shipped,
     profiles/r03_experiments.txt section 10.)"""
     from pano_nerf_amd import _lib
@@ -316,5 +317,5 @@ def test_large_weight_gradient_sums_against_fp64_and_an_fp32_gemm(ray_spread):
         err = {"ours": (g[offs[k]:offs[k] + 65536].double() - want).abs(), "fp32 gemm": (f32 - want).abs()}
         row = {n: (float(e.max()) / top, float((e[big] / want[big].abs()).max())) for n, e in err.items()}
         print(k, {n: "%.2e / %.2e" % v for n, v in row.items()})
-        assert row["ours"][0] < 2e-6 and row["ours"][1] < 1e-4, (k, row)
-        assert row["ours"][0] <= max(row["fp32 gemm"][0], 5e-7), (k, row)
+        assert row["ours"][0] < 2e-6 and row["ours"][0] <= max(row["fp32 gemm"][0], 5e-7), (k, row)
+        assert row["ours"][1] <= max(1e-4, row["fp32 gemm"][1]), (k, row)
