@@ -194,6 +194,13 @@ int pn_mlp_backward(int64_t M, int rows_per_ray, int64_t view_rows, int num_dens
  * two waves per SIMD; the build default) or 32 (v_mfma_f32_32x32x16_bf16, -DPN_CHAIN_TILE=32).  Below, "T layout" means
  * elem[Mp / tile][F][tile]. */
 int pn_chain_tile(void);
+/* "Q24": with planes = 2 and 16-sample tiles, the 256-wide tensors that only pn_chain_wgrad reads back are stored in THREE bytes per
+ * element - fp32 rounded to 16 significant bits (round to nearest on the dropped byte), the four features of a quad block of a
+ * sample in 12 bytes: elem[Mp / 16][F / 4][16][12 B], byte b of a feature's three = bits 8 (b + 1) .. 8 (b + 1) + 7 of the rounded
+ * fp32 - a quarter of the step's HBM traffic in these tensors; each keeps its slot's address (slot * Mp * 256 floats) and uses the
+ * first three quarters of it.  Bit s of the result: slot s of the tensor is Q24; tensor 0: activations h_s (acts_t), 1: tangents
+ * hdot_s (tang_t), 2: deltas (delta_t), 3: reverse-sweep vectors r_s (rs_t).  0 for every other mode: all fp32 (or bf16). */
+int pn_chain_q24_slots(int planes, int tensor);
 int64_t pn_chain_pack_bytes(int planes);
 int pn_chain_pack(const float* params, int num_density_channels, int planes, void* pack, void* stream);
 /* floats of acts_t: h0..h7 [256] x 8, bottleneck | view encoding [288], view hidden [128].  acts_t may be NULL in

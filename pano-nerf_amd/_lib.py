@@ -57,6 +57,7 @@ SIGNATURES = {
     "pn_chain_tangent": ("i", "lii" + "p" * 10 + "p"),
     "pn_chain_backward": ("i", "liif" + "p" * 15 + "p"),
     "pn_chain_wgrad_work_floats": ("l", ""),
+    "pn_chain_q24_slots": ("i", "ii"),
     "pn_chain_wgrad": ("i", "ipiipplp"),
     "pn_mfma_probe": ("i", "piip"),
     "pn_prof_enable": ("i", "i"),

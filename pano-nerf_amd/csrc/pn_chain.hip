@@ -864,6 +864,44 @@ __device__ __forceinline__ void store_t(TE* base, const accv (&acc)[NT]) {
         }
 }
 
+// ---- Q24: a T tensor in THREE bytes per element (round 3) --------------------------------------------------------------
+// The tensors that only the weight-gradient GEMMs read back - h0..h6, hdot_0..6, delta_l and r_l for l = 1-4, 6, 7: 26 of the
+// 32 KB a second-order evaluation writes per sample in its 256-wide vectors - are stored as fp32 ROUNDED TO 16 SIGNIFICANT BITS,
+// the four features of a quad block of a sample in 12 bytes: [block][F / 4][16 samples][12 B].  A quad block of a lane is ONE
+// 12-byte store (768 contiguous bytes per wave instruction) where four dword stores stood, and a quarter of the bytes of the
+// step's HBM traffic in these tensors is gone on both sides - the chains' exposed store time and the weight-gradient GEMMs' read
+// time follow the BYTES (profiles/r03_experiments.txt sections 9, 11, 13).  A 2^-17 rounding error per operand leaves a sum
+// over samples ~1e-6 of its tensor's largest element off, the level of an fp32 GEMM's own summation noise (3e-6 on the same
+// data: tests/test_gpu_chain.py::test_large_weight_gradient_sums_against_fp64_and_an_fp32_gemm); what the chains re-read
+// themselves (encodings, r_5, delta_5) and the narrow tensors stay fp32.  fp16-pair builds with 16-sample tiles only.
+#ifndef PN_NO_Q24  // (-DPN_NO_Q24=1: every T tensor fp32, for A/B measurements)
+#define PN_NO_Q24 0
+#endif
+template <int NP>
+constexpr bool kQ24 = (NP == 2 && TILE == 16 && !PN_NO_Q24);
+__host__ __device__ constexpr bool q24_act(int slot) { return slot <= 6; }                  // h_l / hdot_l
+__host__ __device__ constexpr bool q24_delta(int slot) { return slot != 0 && slot != 5; }   // delta_l / r_l
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ u32x3 pack_q24(float x0, float x1, float x2, float x3) {
+    // round to nearest on the dropped byte (ties away from zero: one tie in 256, a bias of 2^-26), then bytes 1-3 of each element
+    const uint32_t e0 = __float_as_uint(x0) + 0x80u, e1 = __float_as_uint(x1) + 0x80u;
+    const uint32_t e2 = __float_as_uint(x2) + 0x80u, e3 = __float_as_uint(x3) + 0x80u;
+    u32x3 v;
+    v[0] = __builtin_amdgcn_perm(e1, e0, 0x05030201u);
+    v[1] = __builtin_amdgcn_perm(e2, e1, 0x06050302u);
+    v[2] = __builtin_amdgcn_perm(e3, e2, 0x07060503u);
+    return v;
+}
+// byte offset of this lane's part of a Q24 block: quad block qb of the lane is at + qb * 768
+__device__ __forceinline__ int q24_lane(int c, int g) { return g * 192 + c * 12; }
+template <int NT>
+__device__ __forceinline__ void store_q24(unsigned char* base, const accv (&acc)[NT]) {
+    if constexpr (PN_ABL_CHAIN & 16) return;
+#pragma unroll
+    for (int qb = 0; qb < NT * ACCQ; ++qb)
+        *reinterpret_cast<u32x3*>(base + qb * 768) = pack_q24(AQ(acc, qb, 0), AQ(acc, qb, 1), AQ(acc, qb, 2), AQ(acc, qb, 3));
+}
+
 // ReLU gate bits of a lane, MW words (4 with TILE 32, 2 with TILE 16): element j of k-step ks of the lane's B operand is half
 // j & 1 of dword d = 4 ks + (j >> 1) of its packed planes, and its gate is bit (d & 15) + 16 (j & 1) of word d >> 4.  Seen
 // from an accumulator, position i of quad block qb is element 4 (qb & 1) + i of k-step qb >> 1.
@@ -1037,6 +1075,17 @@ __device__ __forceinline__ Tile tile_of(int64_t st, int wid, int lane, int64_t M
     t.lo = t.c + 4 * t.g * TILE;
     return t;
 }
+// T store of an F-feature vector of this wave's tile into the tensor at `slot`: fp32 T layout, or Q24 (`q`: wave-uniform)
+template <int NP, int NT>
+__device__ __forceinline__ void store_vec(typename TEl<NP>::type* slot, const Tile& T, int F, bool q, const accv (&acc)[NT]) {
+    if constexpr (kQ24<NP>) {
+        if (q) {
+            store_q24<NT>(reinterpret_cast<unsigned char*>(slot) + T.blk * (int64_t)(F * TILE * 3) + q24_lane(T.c, T.g), acc);
+            return;
+        }
+    }
+    store_t<NT>(slot + T.blk * (int64_t)(F * TILE) + T.lo, acc);
+}
 
 // integrated positional encoding (MODE 0), or its tangent along v (MODE 1), of this lane's 96 / NG features -> T-layout
 // store + B operand.  Features f and f + 48 (sine / "cosine" of the same argument) sit in the same lane.
@@ -1155,9 +1204,10 @@ __device__ __forceinline__ void ipe_backward_tiles(const accv (&acc)[NT_ENC], co
 }
 // gate, T-layout store and next B operand of a 256-wide hidden vector (backward-direction sweeps and the tangent sweep)
 template <int NP>
-__device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, typename TEl<NP>::type* out, BFrag<NP> (&bh)[KS_H]) {
+__device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, typename TEl<NP>::type* slot, const Tile& T, bool q24,
+                                           BFrag<NP> (&bh)[KS_H]) {
     gate_bits<NT_H>(acc, m);
-    if (out) store_t<NT_H>(out, acc);  // (wave-uniform)
+    if (slot) store_vec<NP, NT_H>(slot, T, 256, q24, acc);  // (wave-uniform)
     return acc_to_b<NP, NT_H, KS_H>(acc, bh, 0.f, EXP_CAP_Z);  // (backward-direction and tangent sweeps only)
 }
 
@@ -1256,7 +1306,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         }
         auto finish_hidden = [&](int slot) {  // ReLU, T store, next B operand, gate bits
             relu<NT_H>(acc);
-            if (TP(a.acts_t)) store_t<NT_H>(TP(a.acts_t) + act_off(slot, Mp) + T.blk * (256 * TILE) + T.lo, acc);  // (uniform)
+            if (TP(a.acts_t)) store_vec<NP, NT_H>(TP(a.acts_t) + act_off(slot, Mp), T, 256, q24_act(slot), acc);  // (uniform)
             const Ex e = acc_to_b<NP, NT_H, KS_H>(acc, bh);
             gate_words<NP, KS_H, KS_H>(bh, mw);
             store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
@@ -1430,7 +1480,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
             else return 0;
         };
         {  // seed r_7
-            TE* rt = a.keep_all ? TP(a.vec_t) + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo : nullptr;
+            constexpr bool Q7 = kQ24<NP> && q24_delta(7);  // r_7 in three bytes per element: a quad block is one store
+            TE* rt = (a.keep_all && !Q7) ? TP(a.vec_t) + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo : nullptr;
+            unsigned char* rq = (a.keep_all && Q7) ? reinterpret_cast<unsigned char*>(TP(a.vec_t) + (int64_t)7 * Mp * 256) +
+                                                         T.blk * (int64_t)(256 * TILE * 3) + q24_lane(T.c, T.g)
+                                                   : nullptr;
             const Gate m7 = pop_front(mk);
             if constexpr (NP == 2) {  // |r_7| <= softplus'(z) * max |Wd[0]| over this lane's features
                 float wm = 0.f;
@@ -1456,6 +1510,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
                         x[j] = bit ? sgm * wv[i] : 0.f;
                         if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = (TE)x[j];
                     }
+                    if constexpr (Q7) {
+                        if (rq) *reinterpret_cast<u32x3*>(rq + (2 * ks + h) * 768) = pack_q24(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]);
+                    }
                 }
                 split_into<NP>(x, bh[ks], bex);
             }
@@ -1465,7 +1522,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         for (int l = 7; l >= 1; --l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
             TE* dst = a.keep_all ? TP(a.vec_t) + (int64_t)(l - 1) * Mp * 256 : (l - 1 == 5 ? TP(a.vec_t) : nullptr);
-            const Ex e = finish_gated<NP>(acc, pop_front(mk), dst ? dst + T.blk * (256 * TILE) + T.lo : nullptr, bh);
+            const Ex e = finish_gated<NP>(acc, pop_front(mk), dst, T, q24_delta(l - 1), bh);  // (r_5, re-read below, is never Q24)
             bex = e.ex;
             RM.upd(l - 1, e.top);
         }
@@ -1534,13 +1591,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
             RM.upd(8, e.top);
             chain_gemm<NP, KS_ENC, NT_H, false, true>(R, benc, acc, lane, wx(F_L0) + bex);
         }
-        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + T.blk * (256 * TILE) + T.lo, bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t), T, q24_act(0), bh);
         bex = e.ex;
         RM.upd(0, e.top);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L0 + l) + bex);
-            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)l * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)l * Mp * 256, T, q24_act(l), bh);
             bex = e.ex;
             RM.upd(l, e.top);
         }
@@ -1549,12 +1606,12 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
             BFrag<NP> benc[KS_ENC];
             const int eex = reload_b<NP, KS_ENC>(et, benc, EXP_CAP_Z);
             chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane, wx(F_L5E) + eex);
-            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)5 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)5 * Mp * 256, T, q24_act(5), bh);
             bex = e.ex;
             RM.upd(5, e.top);
         }
         chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L6) + bex);
-        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)6 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)6 * Mp * 256, T, q24_act(6), bh);
         bex = e.ex;
         RM.upd(6, e.top);
         chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L7) + bex);
@@ -1700,13 +1757,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
         }
         BFrag<NP> bh[KS_H];
         chain_gemm<NP, KS_H + 1, NT_H, false, true>(R, be, acc, lane, wx(B_EXTRA) + bex);
-        e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)7 * Mp * 256, T, q24_delta(7), bh);
         bex = e.ex;
         RM.upd(7, e.top);
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
-            e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)(l - 1) * Mp * 256 + T.blk * (256 * TILE) + T.lo, bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)(l - 1) * Mp * 256, T, q24_delta(l - 1), bh);
             bex = e.ex;
             RM.upd(l - 1, e.top);
         }
@@ -1797,16 +1854,27 @@ __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<N
 }
 // the T tensors are read once per GEMM: non-temporal loads (4.70 -> 4.57 ms for the GEMMs of one evaluation)
 #define WG_LD(p) __builtin_nontemporal_load(p)
-template <int NP, int TM, int TN, int WM, int WN>
+// Y24 / X24: the operand tensor is stored in Q24 (see pack_q24): its work item is a UNIT of 48 contiguous bytes - four features of
+// four samples - unpacked to fp32 (one byte permute per element) and transposed in registers into four (feature, 4 samples) pieces.
+// With both operands in Q24 the X and Y units form one list over the threads (one unit per thread on the 256 x 256 tile).  The LDS
+// image then holds feature f in row (f & ~3) | ((f + (f >> 2)) & 3): a unit's four writes go to rows 4 qb + f for a fixed f across
+// the wave, which in the plain image are 128 bytes apart - the same eight banks sixteen times.
+template <int NP, int TM, int TN, int WM, int WN, bool X24 = false, bool Y24 = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
+    static_assert(!(X24 || Y24) || (NP == 2 && TILE == 16), "Q24 tensors exist in fp16-pair builds with 16-sample tiles");
+    static_assert(!X24 || Y24, "combinations in use: (0,0), (0,1), (1,1)");
+    constexpr bool ROT = X24 || Y24;  // row permutation of the LDS images
     constexpr int NTH = 64 * WM * WN, TMW = 32 * TM * WM, TNW = 32 * TN * WN;
     constexpr int PX = TMW * 16, PY = TNW * 16;     // bf16 elements per plane
     constexpr int BUF = NP * (PX + PY);             // per buffer
     typedef typename TEl<NP>::type TE;              // element type of the T tensors (bf16 for NP = 1: staging is a copy)
     constexpr int PPR = 16 * (int)sizeof(TE) / 16;  // 16-B pieces per row of 16 samples: 4 (fp32) or 2 (bf16)
     constexpr int SPP = 16 / PPR;                   // samples per piece
-    constexpr int CX = TMW * PPR, CY = TNW * PPR;   // 16-B pieces per half block
-    constexpr int LX = (CX + NTH - 1) / NTH, LY = (CY + NTH - 1) / NTH;
+    constexpr int CX = X24 ? 0 : TMW * PPR, CY = Y24 ? 0 : TNW * PPR;   // 16-B pieces per half block (fp32 / bf16 operands)
+    constexpr int LX = X24 ? 1 : (CX + NTH - 1) / NTH, LY = Y24 ? 1 : (CY + NTH - 1) / NTH;  // (1: a dummy register)
+    constexpr int UX = X24 ? TMW : 0, UY = Y24 ? TNW : 0;               // Q24 units per half block
+    constexpr int LU = (UX + UY + NTH - 1) / NTH;                       // units per thread (X units first, then Y units)
+    static_assert(UX % 64 == 0, "a wave's units are all X or all Y");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1825,12 +1893,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     float bsum[LX];
 #pragma unroll
     for (int i = 0; i < LX; ++i) bsum[i] = 0.f;
+    float bsum4[LU > 0 ? LU : 1][4] = {};  // X24: row sums of a unit's four features
 
     // NSET register sets: the loads of half block h + NSET are issued when h's set has been staged, so they have NSET
     // half blocks to land (one workgroup per CU: nothing else hides the HBM latency).  Three where the registers allow:
     // with three products per fp32 product the kernel is HBM-bound and two sets keep only 32-64 KB per CU in flight.
-    constexpr int NSET = (NP <= 2 && LX + LY <= 4) ? 3 : 2;
+#ifndef PN_WG_Q24_NSET
+#define PN_WG_Q24_NSET 4
+#endif
+    // (both operands in Q24: a thread holds ONE 48-byte unit per set - four sets are the 48 registers of three fp32 sets)
+    constexpr int NSET = (X24 && LU == 1) ? PN_WG_Q24_NSET : ((NP <= 2 && (X24 ? 0 : LX) + (Y24 ? 0 : LY) + 3 * LU <= 4) ? 3 : 2);
     f32x4 xr[NSET][LX], yr[NSET][LY];
+    f32x4 ur[NSET][LU > 0 ? LU : 1][3];  // a unit: 48 bytes
     float bw[NSET] = {};  // bias weight of the half block held in each set
     // NP = 2: ONE unit for the whole job, 2^unit = the scale of every product in the accumulators: the smallest sx + sy over
     // the job's segments (the segment with the LARGEST products).  A segment whose own exponents add up to more is scaled
@@ -1886,15 +1960,33 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         const int half = (int)(hb % (TILE / 16));
         const TE* xb = cX + blk * ((int64_t)cFX * TILE) + half * 16;
         const TE* yb = cY + blk * ((int64_t)cFY * TILE) + half * 16;
+        if constexpr (!X24) {
 #pragma unroll
-        for (int i = 0; i < LX; ++i) {
-            const int idx = tid + NTH * i;
-            if (CX % NTH == 0 || idx < CX) xr[set][i] = WG_LD(reinterpret_cast<const f32x4*>(xb + (idx / PPR) * TILE + (idx % PPR) * SPP));
+            for (int i = 0; i < LX; ++i) {
+                const int idx = tid + NTH * i;
+                if (CX % NTH == 0 || idx < CX) xr[set][i] = WG_LD(reinterpret_cast<const f32x4*>(xb + (idx / PPR) * TILE + (idx % PPR) * SPP));
+            }
         }
+        if constexpr (!Y24) {
 #pragma unroll
-        for (int i = 0; i < LY; ++i) {
-            const int idx = tid + NTH * i;
-            if (CY % NTH == 0 || idx < CY) yr[set][i] = WG_LD(reinterpret_cast<const f32x4*>(yb + (idx / PPR) * TILE + (idx % PPR) * SPP));
+            for (int i = 0; i < LY; ++i) {
+                const int idx = tid + NTH * i;
+                if (CY % NTH == 0 || idx < CY) yr[set][i] = WG_LD(reinterpret_cast<const f32x4*>(yb + (idx / PPR) * TILE + (idx % PPR) * SPP));
+            }
+        }
+        if constexpr (X24 || Y24) {  // (TILE 16: a block is one half block; a Q24 block of F features is F * 48 bytes, a unit 48)
+            const unsigned char* xq = reinterpret_cast<const unsigned char*>(cX) + blk * ((int64_t)cFX * 48);
+            const unsigned char* yq = reinterpret_cast<const unsigned char*>(cY) + blk * ((int64_t)cFY * 48);
+#pragma unroll
+            for (int i = 0; i < LU; ++i) {
+                const int u = tid + NTH * i;
+                if ((UX + UY) % NTH == 0 || u < UX + UY) {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(u < UX ? xq + u * 48 : yq + (u - UX) * 48);  // (wave-uniform)
+                    ur[set][i][0] = WG_LD(p);
+                    ur[set][i][1] = WG_LD(p + 1);
+                    ur[set][i][2] = WG_LD(p + 2);
+                }
+            }
         }
     };
     auto put = [&](unsigned short* plane0, int pstride, int idx, const f32x4& v, int ex) {
@@ -1903,7 +1995,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             *reinterpret_cast<f32x4*>(plane0 + f * 16 + ((q ^ ((f >> 3) & 1)) << 3)) = v;
             return;
         }
-        const int f = idx >> 2, q = idx & 3;
+        const int f0 = idx >> 2, q = idx & 3;
+        const int f = ROT ? ((f0 & ~3) | ((f0 + (f0 >> 2)) & 3)) : f0;
         const int o = f * 16 + (((q >> 1) ^ ((f >> 3) & 1)) << 3) + (q & 1) * 4;
         if constexpr (NP == 2) {
             const float s = pow2f(ex);
@@ -1933,9 +2026,46 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             }
         }
     };
+    // a Q24 unit -> four (feature, 4 samples) pieces of the image at `plane0`; `bs`: the unit's row sums (X with bias) or null
+    auto put_unit = [&](unsigned short* plane0, int pstride, int u, const f32x4 (&r)[3], int ex, float* bs, float w) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        uint32_t d[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const u32x4 t = __builtin_bit_cast(u32x4, r[k]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[4 * k + c] = t[c];
+        }
+        float e[4][4];  // [sample][feature]
+#pragma unroll
+        for (int sm = 0; sm < 4; ++sm) {
+            e[sm][0] = __uint_as_float(d[3 * sm] << 8);
+            e[sm][1] = __uint_as_float(__builtin_amdgcn_perm(d[3 * sm + 1], d[3 * sm], 0x0504030cu));
+            e[sm][2] = __uint_as_float(__builtin_amdgcn_perm(d[3 * sm + 2], d[3 * sm + 1], 0x0403020cu));
+            e[sm][3] = __uint_as_float(d[3 * sm + 2] & 0xffffff00u);
+        }
+        const int qb = u >> 2, sg = u & 3;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const f32x4 v{e[0][f], e[1][f], e[2][f], e[3][f]};
+            put(plane0, pstride, (4 * qb + f) * 4 + sg, v, ex);
+            if (bs) bs[f] += w * ((v[0] + v[1]) + (v[2] + v[3]));
+        }
+    };
     auto stage = [&](int buf, int set) __attribute__((always_inline)) {
         unsigned short* xs = smem + buf * BUF;
         unsigned short* ys = xs + NP * PX;
+        if constexpr (X24 || Y24) {
+#pragma unroll
+            for (int i = 0; i < LU; ++i) {
+                const int u = tid + NTH * i;
+                if ((UX + UY) % NTH == 0 || u < UX + UY) {
+                    if (u < UX) put_unit(xs, PX, u, ur[set][i], sx[set], bsum4[i], bw[set]);  // (wave-uniform)
+                    else put_unit(ys, PY, u - UX, ur[set][i], sy[set], nullptr, 0.f);
+                }
+            }
+        }
+        if constexpr (!X24)
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = tid + NTH * i;
@@ -1952,6 +2082,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
                 }
             }
         }
+        if constexpr (!Y24)
 #pragma unroll
         for (int i = 0; i < LY; ++i) {
             const int idx = tid + NTH * i;
@@ -1960,6 +2091,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     };
     const int fr = lane & 31, fh = lane >> 5;
     auto frag = [&](const unsigned short* plane, int feature) {
+        if constexpr (ROT) feature = (feature & ~3) | ((feature + (feature >> 2)) & 3);
         return *reinterpret_cast<const typename PlaneOf<NP>::type*>(plane + feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3));
     };
     auto compute = [&](int buf) __attribute__((always_inline)) {
@@ -1993,10 +2125,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #pragma unroll
         for (int k = 0; k < NSET; ++k)
             if (h0 + k < h1) load(h0 + k, k);
-        constexpr int TRIP = NSET == 3 ? 6 : 2;
+        constexpr int TRIP = NSET == 3 ? 6 : (NSET == 4 ? 4 : 2);  // a multiple of the sets and of the two LDS buffers
         for (int64_t h = h0; h < h1; h += TRIP) {
             one(std::integral_constant<int, 0>{}, h);
             one(std::integral_constant<int, 1>{}, h);
+            if constexpr (TRIP == 4) {
+                one(std::integral_constant<int, 2>{}, h);
+                one(std::integral_constant<int, 3>{}, h);
+            }
             if constexpr (TRIP == 6) {
                 one(std::integral_constant<int, 2>{}, h);
                 one(std::integral_constant<int, 3>{}, h);
@@ -2016,7 +2152,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
                 const float x = acc[i][j][e];
                 out[(int64_t)row * TNW + 32 * (wn * TN + j) + fr] = NP == 2 ? ldexpf(x, -unit) : x;
             }
-    if (a.bias) {
+    if constexpr (X24) {
+        if (a.bias) {
+#pragma unroll
+            for (int i = 0; i < LU; ++i) {
+                const int u = tid + NTH * i;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float v = bsum4[i][f];
+                    v += __shfl_xor(v, 1, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    if ((u & 3) == 0 && u < UX) out[(int64_t)TMW * TNW + 4 * (u >> 2) + f] = v;
+                }
+            }
+        }
+    } else if (a.bias) {
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             float v = bsum[i];
@@ -2220,6 +2370,7 @@ struct WgJob {
     int rows, cols;     // valid part of the result
     float* dst; int ldd;
     float* dbias;       // or null
+    int fmt;            // cfg 0, fp16 pairs: 0 both operands fp32, 1 Y in Q24, 3 X and Y in Q24 (see pack_q24)
 };
 static const int kCfgM[5] = {256, 256, 128, 32, 32};
 static const int kCfgN[5] = {256, 96, 288, 256, 128};
@@ -2296,7 +2447,14 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     {
     PnProfScope prof(6 + j.cfg, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone (not the slab reduction)
     switch (j.cfg) {
-        case 0: hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a); break;
+        case 0:
+            if constexpr (kQ24<NP>) {
+                if (j.fmt == 3) { hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2, true, true>), grid, dim3(512), 0, s, a); break; }
+                if (j.fmt == 1) { hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2, false, true>), grid, dim3(512), 0, s, a); break; }
+            }
+            if (j.fmt != 0) return PN_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((k_chain_wgrad<NP, 2, 4, 4, 2>), grid, dim3(512), 0, s, a);
+            break;
         case 1: hipLaunchKernelGGL((k_chain_wgrad<NP, 1, 3, 8, 1>), grid, dim3(512), 0, s, a); break;
         // (128 x 288 by twelve waves of 1 x 3 tiles: as four waves of 1 x 9 it held 392 registers per lane - one wave per
         // SIMD, two register sets in flight - and ran 3.8 TB/s)
@@ -2317,6 +2475,14 @@ extern "C" {
 
 /* samples per T-layout block (= samples per wave of the chain kernels): 16 or 32 */
 int pn_chain_tile(void) { return TILE; }
+
+int pn_chain_q24_slots(int planes, int tensor) {
+    if (planes != 2 || !kQ24<2> || tensor < 0 || tensor > 3) return 0;
+    int m = 0;
+    for (int sl = 0; sl < 8; ++sl)
+        if (tensor < 2 ? q24_act(sl) : q24_delta(sl)) m |= 1 << sl;
+    return m;
+}
 
 // bytes of the packed chains for `planes` (3: exact split, 1: plain bf16): [forward chain | backward chain]
 int64_t pn_chain_pack_bytes(int planes) {
@@ -2498,6 +2664,8 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
                                        l == 0 ? 96 : 256, 0, am(e, AM_RS0 + l), am(e, l == 0 ? AM_EDOT : AM_TANG0 + l - 1)};
         }
         j.cfg = l == 0 ? 1 : 0;
+        // fp16 pairs: delta_l / r_l (l = 1-4, 6, 7) and h_{l-1} / hdot_{l-1} (l >= 1) come in Q24
+        j.fmt = (planes == 2 && kQ24<2> && l >= 1) ? (q24_delta(l) ? 3 : 1) : 0;
         j.rows = 256;
         j.cols = l == 0 ? 96 : 256;
         j.dst = grads + L.w[l];

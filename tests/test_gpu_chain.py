@@ -11,6 +11,7 @@ import torch
 
 from oracle import pano_oracle as orc
 from test_gpu_grads import gates_of
+from pano_nerf_amd import tlayout as tl
 
 pytestmark = pytest.mark.gpu
 
@@ -211,10 +212,17 @@ def test_weight_gradients_over_segments_whose_magnitudes_are_1e30_apart(order):
         amax[AM["d8b"]], amax[AM["d8d"]] = d8[:, :256].abs().max(), d8[:, 256:].abs().max()
         amax[AM["dhv"]], amax[AM["drgb"]] = dhv.abs().max(), drgb.abs().max()
         dv = lambda t: t.to(dev())
-        bufs = dict(enc_t=dv(t_of(enc)),
-                    acts_t=dv(torch.cat([t_of(a) for a in acts])),
+        qa, qd = int(lib.pn_chain_q24_slots(2, 0)), int(lib.pn_chain_q24_slots(2, 2))  # slots stored in three bytes per element
+        acts_buf = torch.zeros(8 * Mp * 256 + Mp * 288 + Mp * 128)
+        for i, a_ in enumerate(acts):
+            off = i * Mp * 256 if i <= 8 else 8 * Mp * 256 + Mp * 288
+            tl.write_slot(lib, acts_buf[off:off + Mp * a_.shape[1]], a_, i < 8 and bool(qa >> i & 1))
+        delta_buf = torch.zeros(8 * Mp * 256)
+        for i, d_ in enumerate(delta):
+            tl.write_slot(lib, delta_buf[i * Mp * 256:(i + 1) * Mp * 256], d_, bool(qd >> i & 1))
+        bufs = dict(enc_t=dv(t_of(enc)), acts_t=dv(acts_buf),
                     drgb_t=dv(t_of(drgb)), dhv_t=dv(t_of(dhv)), d8_t=dv(t_of(d8)),
-                    delta_t=dv(torch.cat([t_of(d) for d in delta])), amax=dv(amax.view(torch.int32)))
+                    delta_t=dv(delta_buf), amax=dv(amax.view(torch.int32)))
         keep.append(bufs)
         evs.append(EvalC(M, bufs["enc_t"].data_ptr(), bufs["acts_t"].data_ptr(), bufs["drgb_t"].data_ptr(), bufs["dhv_t"].data_ptr(),
                          bufs["d8_t"].data_ptr(), bufs["delta_t"].data_ptr(), None, None, None, None, bufs["amax"].data_ptr()))
@@ -244,7 +252,9 @@ def test_weight_gradients_over_segments_whose_magnitudes_are_1e30_apart(order):
     assert np.isfinite(got).all()
     for k in ORDER:
         e = rel(got[offs[k]:offs[k] + shapes[k]], want[k])
-        assert e < 1e-5, (k, e)
+        # 1e-5 where both operands are fp32 tensors; the trunk layers' operands are stored in three bytes per element (2^-16 per
+        # operand): the sum of 1024 such products is gated at 3e-5 of the tensor's largest element
+        assert e < (3e-5 if k.startswith("layers.") and not k.startswith("layers.0.") else 1e-5), (k, e)
 
 
 def _synthetic_eval(lib, M, nc, gen, ray_spread):
@@ -271,8 +281,16 @@ def _synthetic_eval(lib, M, nc, gen, ray_spread):
         amax[AM["delta"] + i] = dl.abs().max()
     amax[AM["d8b"]], amax[AM["d8d"]] = d8[:, :256].abs().max(), d8[:, 256:].abs().max()
     amax[AM["dhv"]], amax[AM["drgb"]] = dhv.abs().max(), drgb.abs().max()
-    bufs = dict(enc_t=t_of(enc), acts_t=torch.cat([t_of(a) for a in acts]), drgb_t=t_of(drgb), dhv_t=t_of(dhv), d8_t=t_of(d8),
-                delta_t=torch.cat([t_of(x) for x in delta]), amax=amax.view(torch.int32))
+    qa, qd = int(lib.pn_chain_q24_slots(2, 0)), int(lib.pn_chain_q24_slots(2, 2))  # slots stored in three bytes per element
+    acts_buf = torch.zeros(8 * Mp * 256 + Mp * 288 + Mp * 128, device=d)
+    for i, a_ in enumerate(acts):
+        off = i * Mp * 256 if i <= 8 else 8 * Mp * 256 + Mp * 288
+        tl.write_slot(lib, acts_buf[off:off + Mp * a_.shape[1]], a_, i < 8 and bool(qa >> i & 1))
+    delta_buf = torch.zeros(8 * Mp * 256, device=d)
+    for i, d_ in enumerate(delta):
+        tl.write_slot(lib, delta_buf[i * Mp * 256:(i + 1) * Mp * 256], d_, bool(qd >> i & 1))
+    bufs = dict(enc_t=t_of(enc), acts_t=acts_buf, drgb_t=t_of(drgb), dhv_t=t_of(dhv), d8_t=t_of(d8),
+                delta_t=delta_buf, amax=amax.view(torch.int32))
     ev = EvalC(M, bufs["enc_t"].data_ptr(), bufs["acts_t"].data_ptr(), bufs["drgb_t"].data_ptr(), bufs["dhv_t"].data_ptr(),
                bufs["d8_t"].data_ptr(), bufs["delta_t"].data_ptr(), None, None, None, None, bufs["amax"].data_ptr())
     pairs = {}  # the 256 x 256 sums: (delta rows, input rows)
@@ -284,15 +302,18 @@ def _synthetic_eval(lib, M, nc, gen, ray_spread):
 
 @pytest.mark.parametrize("ray_spread", [0.0, 2.0])
 def test_large_weight_gradient_sums_against_fp64_and_an_fp32_gemm(ray_spread):
-    """The 256 x 256 weight-gradient tile (fp16 pairs, three products per fp32 product) on sums over 2^17 samples, against the
-    fp64 product of the same T tensors and next to an fp32 GEMM of the same operands (torch.matmul: the reference's arithmetic,
-    models/pano_mip_nerf.py:95-114 through autograd).  Deltas zero-mean and half gated - the sums cancel to ~sqrt(M) terms, the
-    hard case for a rounding error per term; ray_spread = 2: a few percent of the rays carry most of every sum.
-    Gates: every element within 2e-6 of the tensor's largest and no worse than the fp32 GEMM's own error there; element-wise, where
-    |ref| > 1e-3 max, within 1e-4 or the fp32 GEMM's own element-wise error (an fp32 result 1000 x below the tensor's largest element
-    that is a cancelling sum of 2^17 terms is not known to 1e-4 by EITHER arithmetic: measured 1.7e-4 ours, 8.8e-4 the fp32 GEMM).  (A LEAN form - the delta operand as its leading fp16 half only, two products - was measured here in
-    round 3: 13 % faster, 1.9e-4 of the tensor's largest element off, 60 x the fp32 GEMM's error: not shipped,
-    profiles/r03_experiments.txt section 10.)"""
+    """The 256 x 256 weight-gradient tile (fp16 pairs, three products per fp32 product; operands read from Q24 tensors - fp32
+    rounded to 16 significant bits - where pn_chain_q24_slots says so) on sums over 2^17 samples, against the fp64 product of
+    the UNROUNDED tensors and next to an fp32 GEMM of them (torch.matmul: the reference's arithmetic, models/pano_mip_nerf.py:
+    95-114 through autograd).  Deltas zero-mean and half gated - the sums cancel to ~sqrt(M) terms, the hard case for a rounding
+    error per term; ray_spread = 2: a few percent of the rays carry most of every sum.
+    Measured, largest error over a tensor / its largest element: fp32 GEMM 2.5 - 4.5e-6; this tile on fp32 tensors 2.6 - 5.3e-7
+    (the extra layer's job, whose operands stay fp32); on Q24 tensors 0.8 - 1.1e-5 - a tenth of the path's 1e-4.  Gates: 2e-6 /
+    3e-5 of the tensor's largest element (fp32 / Q24 operands); element-wise, where |ref| > 1e-3 max, within 1e-4 or the fp32
+    GEMM's own element-wise error for fp32 operands (a result 1000 x below the tensor's largest element that is a cancelling sum
+    of 2^17 terms is not known to 1e-4 by EITHER arithmetic: 1.7e-4 against 8.8e-4).
+    (A LEAN form - the delta operand as its leading fp16 half only, two products - was measured here in round 3: 13 % faster,
+    1.9e-4 of the tensor's largest element off, 60 x the fp32 GEMM's error: not shipped, profiles/r03_experiments.txt section 10.)"""
     from pano_nerf_amd import _lib
     from pano_nerf_amd.mlp import param_layout
     lib = _lib.load()
@@ -317,5 +338,9 @@ def test_large_weight_gradient_sums_against_fp64_and_an_fp32_gemm(ray_spread):
         err = {"ours": (g[offs[k]:offs[k] + 65536].double() - want).abs(), "fp32 gemm": (f32 - want).abs()}
         row = {n: (float(e.max()) / top, float((e[big] / want[big].abs()).max())) for n, e in err.items()}
         print(k, {n: "%.2e / %.2e" % v for n, v in row.items()})
-        assert row["ours"][0] < 2e-6 and row["ours"][0] <= max(row["fp32 gemm"][0], 5e-7), (k, row)
-        assert row["ours"][1] <= max(1e-4, row["fp32 gemm"][1]), (k, row)
+        q24 = k != "extra_layer.weight" and int(lib.pn_chain_q24_slots(2, 0)) != 0
+        if q24:
+            assert row["ours"][0] < 3e-5, (k, row)
+        else:
+            assert row["ours"][0] < 2e-6 and row["ours"][0] <= max(row["fp32 gemm"][0], 5e-7), (k, row)
+            assert row["ours"][1] <= max(1e-4, row["fp32 gemm"][1]), (k, row)

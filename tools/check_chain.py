@@ -28,6 +28,15 @@ def t32_to_rows(t, Mp, F):
     return TS(t)[:Mp * F].float().reshape(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
 
 
+def slot_to_rows(buf, l, Mp, kind):
+    """256-wide slot l of tensor `kind` (0 acts, 1 tangents, 2 deltas, 3 reverse sweep), fp32 T layout or Q24 as the mode stores it."""
+    from pano_nerf_amd import tlayout
+    lib.pn_chain_q24_slots.argtypes = [__import__("ctypes").c_int] * 2
+    if (int(lib.pn_chain_q24_slots(_PLANES, kind)) >> l) & 1:
+        return tlayout.q24_decode(buf.reshape(-1)[l * Mp * 256:(l + 1) * Mp * 256].view(torch.uint8), Mp, 256)
+    return t32_to_rows(TS(buf)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)
+
+
 def run(M, rows_per_ray, planes, nc=5, reps=0):
     global _PLANES
     _PLANES = planes
@@ -73,7 +82,7 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     print(f"M={M} planes={planes}")
     print("  enc      ", rel(t32_to_rows(enc_t, Mp, 96)[:M], enc[:M]))
     for l in range(8):
-        h = t32_to_rows(TS(acts_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
+        h = slot_to_rows(acts_t, l, Mp, 0)[:M]
         print(f"  h{l}       ", rel(h, acts[l, :M]))
     b = t32_to_rows(TS(acts_t)[8 * Mp * 256:8 * Mp * 256 + Mp * 288], Mp, 288)[:M]
     print("  bott     ", rel(b[:, :256], acts[8, :M]))
@@ -86,7 +95,7 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     tile = int(lib.pn_chain_tile()); ng = 64 // tile; qbs = 4 * ng
     bad = 0
     for l in (0, 5, 7):
-        h = t32_to_rows(TS(acts_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M]
+        h = slot_to_rows(acts_t, l, Mp, 0)[:M]
         for f in (0, 5, 37, 100, 131, 255):
             qb, g, i = f // qbs, (f % qbs) // 4, f % 4
             d = 4 * (qb >> 1) + ((4 * (qb & 1) + i) >> 1)  # dword of the packed B operand holding the element (pn_chain.hip: gate_word / gate_bit)

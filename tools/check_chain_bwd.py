@@ -29,6 +29,15 @@ def t32_to_rows(t, Mp, F):
     return TS(t)[:Mp * F].float().reshape(Mp // tile, F, tile).permute(0, 2, 1).reshape(Mp, F)
 
 
+def slot_to_rows(buf, l, Mp, kind):
+    """256-wide slot l of tensor `kind` (0 acts, 1 tangents, 2 deltas, 3 reverse sweep), fp32 T layout or Q24 as the mode stores it."""
+    from pano_nerf_amd import tlayout
+    lib.pn_chain_q24_slots.argtypes = [__import__("ctypes").c_int] * 2
+    if (int(lib.pn_chain_q24_slots(_PLANES, kind)) >> l) & 1:
+        return tlayout.q24_decode(buf.reshape(-1)[l * Mp * 256:(l + 1) * Mp * 256].view(torch.uint8), Mp, 256)
+    return t32_to_rows(TS(buf)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)
+
+
 def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
@@ -102,14 +111,14 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     print(f"M={M} planes={planes}")
     print("  grad_mean ", rel(gmean2, gmean))
     for l in (7, 5, 3, 0):
-        print(f"  r{l}        ", rel(t32_to_rows(TS(rs_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M], rsweep[l, :M]))
+        print(f"  r{l}        ", rel(slot_to_rows(rs_t, l, Mp, 3)[:M], rsweep[l, :M]))
     print("  edot      ", rel(t32_to_rows(edot_t, Mp, 96)[:M], edot[:M]))
     for l in (0, 4, 5, 7):
-        print(f"  hdot{l}     ", rel(t32_to_rows(TS(tang_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M], tbuf[l, :M]))
+        print(f"  hdot{l}     ", rel(slot_to_rows(tang_t, l, Mp, 1)[:M], tbuf[l, :M]))
     d8 = t32_to_rows(d8_t, Mp, 288)[:M]
     print("  d_bott    ", rel(d8[:, :256], dbott[:M]))
     for l in (7, 6, 5, 1, 0):
-        print(f"  delta{l}    ", rel(t32_to_rows(TS(delta_t)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)[:M], dbuf[l, :M]))
+        print(f"  delta{l}    ", rel(slot_to_rows(delta_t, l, Mp, 2)[:M], dbuf[l, :M]))
     print("  d_mean    ", rel(d_mean2, d_mean))
     # second-order addend and padded tensors
     z = rd2[:, 0] + dbias
