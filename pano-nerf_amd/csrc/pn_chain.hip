@@ -2123,10 +2123,38 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     };
     if (h0 < h1) {
 #pragma unroll
-        for (int k = 0; k < NSET; ++k)
-            if (h0 + k < h1) load(h0 + k, k);
+        for (int k = 0; k < NSET; ++k) {
+            if constexpr (X24) load(h0 + k < h1 ? h0 + k : h1 - 1, k);  // (unconditional: see the steady-state loop below)
+            else if (h0 + k < h1) load(h0 + k, k);
+        }
         constexpr int TRIP = NSET == 3 ? 6 : (NSET == 4 ? 4 : 2);  // a multiple of the sets and of the two LDS buffers
-        for (int64_t h = h0; h < h1; h += TRIP) {
+        int64_t hs = h0;
+        if constexpr (X24) {
+            // Whole trips without a condition: every half block refills its set (past the end: the last half block again), so that
+            // hipcc can COUNT the loads in flight - behind a conditional `load` it drains the prefetched sets in front of every
+            // staging phase (vmcnt(2), (1), (0) with twelve loads in flight: the memory latency once per half block).
+            auto steady = [&](auto kc, int64_t h) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                stage(K % 2, K % NSET);
+                __syncthreads();
+                const int64_t hn = h + K + NSET;
+                load(hn < h1 ? hn : h1 - 1, K % NSET);
+                compute(K % 2);
+            };
+            for (; hs + TRIP <= h1; hs += TRIP) {
+                steady(std::integral_constant<int, 0>{}, hs);
+                steady(std::integral_constant<int, 1>{}, hs);
+                if constexpr (TRIP >= 4) {
+                    steady(std::integral_constant<int, 2>{}, hs);
+                    steady(std::integral_constant<int, 3>{}, hs);
+                }
+                if constexpr (TRIP == 6) {
+                    steady(std::integral_constant<int, 4>{}, hs);
+                    steady(std::integral_constant<int, 5>{}, hs);
+                }
+            }
+        }
+        for (int64_t h = hs; h < h1; h += TRIP) {
             one(std::integral_constant<int, 0>{}, h);
             one(std::integral_constant<int, 1>{}, h);
             if constexpr (TRIP == 4) {
