@@ -157,9 +157,12 @@ def main():
     peak_chain = PEAK_BF16_MFMA_TFLOPS / {3: 6.0, 2: 3.0, 1: 1.0}[np_]
     # names as rocprofv3 prints them (profiles/*_kernel_stats.csv, profiles/r02_pmc_summary.json)
     CLASSES = ((0, "k_gemm_nt"), (1, "k_gemm_tn"), (2, f"k_chain_fwd<{np_}>"), (3, f"k_chain_dgrad<{np_}>"),
-               (4, f"k_chain_tangent<{np_}>"), (5, f"k_chain_bwd<{np_}>"), (6, f"k_chain_wgrad<{np_}, 2, 4, 4, 2>"),
-               (7, f"k_chain_wgrad<{np_}, 1, 3, 8, 1>"), (8, f"k_chain_wgrad<{np_}, 1, 3, 4, 3>"),
-               (9, f"k_chain_wgrad<{np_}, 1, 2, 1, 4>"), (10, f"k_chain_wgrad<{np_}, 1, 1, 1, 4>"))
+               (4, f"k_chain_tangent<{np_}>"), (5, f"k_chain_bwd<{np_}>"),
+               (6, f"k_chain_wgrad<{np_}, 2, 4, 4, 2, false, false>"), (7, f"k_chain_wgrad<{np_}, 1, 3, 8, 1, false, false>"),
+               (8, f"k_chain_wgrad<{np_}, 1, 3, 4, 3, false, false>"), (9, f"k_chain_wgrad<{np_}, 1, 2, 1, 4, false, false>"),
+               (10, f"k_chain_wgrad<{np_}, 1, 1, 1, 4, false, false>"),
+               # the 256 x 256 tile with operand tensors in three bytes per element ("Q24": Y only / X and Y)
+               (11, f"k_chain_wgrad<{np_}, 2, 4, 4, 2, false, true>"), (12, f"k_chain_wgrad<{np_}, 2, 4, 4, 2, true, true>"))
 
     def read_prof():
         res = {}
@@ -387,12 +390,15 @@ def main():
                      "algorithmic_tflops": achieved, "frac_algorithmic": achieved / peak_dom,
                      "partial_products_per_fp32_product": prod}
         roof_hbm = None
-        if dom.startswith("k_chain_wgrad") and dom.endswith("2, 4, 4, 2>"):
-            # the 256 x 256 weight-gradient tile reads 4 (256 + 256) bytes per sample row (2 with bf16 tensors) for 2 * 256 * 256 FLOP
-            esz = 2.0 if args.mlp_mode == "fused_bf16" else 4.0  # bytes per element of the sample tensors in this mode
-            gbs = fl / (2.0 * 256 * 256) * esz * 512 / max(ms, 1e-9) / 1e6  # algorithmic bytes / time, GB/s
+        if dom.startswith("k_chain_wgrad") and ", 2, 4, 4, 2," in dom:
+            # the 256 x 256 weight-gradient tile reads (256 ex + 256 ey) bytes per sample row for 2 * 256 * 256 FLOP: 4 bytes per
+            # element of an fp32 tensor, 3 of a Q24 tensor, 2 with bf16 tensors
+            esz = 2.0 if args.mlp_mode == "fused_bf16" else 4.0
+            ex, ey = (3.0 if dom.endswith("true, true>") else esz), (3.0 if dom.endswith("true>") else esz)
+            row_bytes = 256 * (ex + ey)
+            gbs = fl / (2.0 * 256 * 256) * row_bytes / max(ms, 1e-9) / 1e6  # algorithmic bytes / time, GB/s
             roof_hbm = {"achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS,
-                        "algorithmic_bytes_per_launch": fl / max(n, 1) / (2.0 * 256 * 256) * esz * 512}
+                        "algorithmic_bytes_per_launch": fl / max(n, 1) / (2.0 * 256 * 256) * row_bytes}
         bound = "mfma"
         top = roof_mfma
         traffic, pmc_tab, pmc_src = None, {}, None

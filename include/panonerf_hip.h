@@ -337,7 +337,7 @@ int pn_gemm_tn(int64_t M, int N1, int N2, const float* X, int ldx, const float* 
  * events on its own stream (the other bits are ignored: the ablation switches of the tools/ micro-benchmarks exist only
  * in -DPN_ABLATE builds).  pn_prof_read waits for the recorded events and returns, for kernel class cls (0 k_gemm_nt,
  * 1 k_gemm_tn, 2 k_chain_fwd, 3 k_chain_dgrad, 4 k_chain_tangent, 5 k_chain_bwd, 6..10 k_chain_wgrad by tile configuration
- * 256x256 / 256x96 / 128x288 / 32x256 / 32x128), the summed duration in ms, the launch count and the summed algorithmic FLOPs (2*M*N*K, unpadded). */
+ * 256x256 / 256x96 / 128x288 / 32x256 / 32x128 on fp32 tensors; 11 / 12 the 256x256 tile with Y / with X and Y in Q24), the summed duration in ms, the launch count and the summed algorithmic FLOPs (2*M*N*K, unpadded). */
 /* diagnostic: `blocks` workgroups x 4 waves each issue 4*iters back-to-back fp32 MFMAs (no memory traffic) */
 int pn_mfma_probe(float* out, int blocks, int iters, void* stream);
 int pn_prof_enable(int on);

@@ -1901,6 +1901,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #ifndef PN_WG_Q24_NSET
 #define PN_WG_Q24_NSET 4
 #endif
+#ifndef PN_WG_Q24_STEADY  // 1: whole trips without a condition (see the loop); measured slower in the training step, off
+#define PN_WG_Q24_STEADY 0
+#endif
     // (both operands in Q24: a thread holds ONE 48-byte unit per set - four sets are the 48 registers of three fp32 sets)
     constexpr int NSET = (X24 && LU == 1) ? PN_WG_Q24_NSET : ((NP <= 2 && (X24 ? 0 : LX) + (Y24 ? 0 : LY) + 3 * LU <= 4) ? 3 : 2);
     f32x4 xr[NSET][LX], yr[NSET][LY];
@@ -2124,15 +2127,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     if (h0 < h1) {
 #pragma unroll
         for (int k = 0; k < NSET; ++k) {
-            if constexpr (X24) load(h0 + k < h1 ? h0 + k : h1 - 1, k);  // (unconditional: see the steady-state loop below)
+            if constexpr (X24 && PN_WG_Q24_STEADY) load(h0 + k < h1 ? h0 + k : h1 - 1, k);  // (unconditional: see the steady-state loop below)
             else if (h0 + k < h1) load(h0 + k, k);
         }
         constexpr int TRIP = NSET == 3 ? 6 : (NSET == 4 ? 4 : 2);  // a multiple of the sets and of the two LDS buffers
         int64_t hs = h0;
-        if constexpr (X24) {
+        if constexpr (X24 && PN_WG_Q24_STEADY) {
             // Whole trips without a condition: every half block refills its set (past the end: the last half block again), so that
             // hipcc can COUNT the loads in flight - behind a conditional `load` it drains the prefetched sets in front of every
-            // staging phase (vmcnt(2), (1), (0) with twelve loads in flight: the memory latency once per half block).
+            // staging phase (vmcnt(2), (1), (0) with twelve loads in flight) where this form gets vmcnt(9) / (6).  Measured on one
+            // box in the training step (multi-segment jobs of 1.9 M rows): 827 - 831 us per launch against 807 us for the
+            // conditional form with four sets (861 with three) - the waits are not what the half block's time is made of.
             auto steady = [&](auto kc, int64_t h) __attribute__((always_inline)) {
                 constexpr int K = decltype(kc)::value;
                 stage(K % 2, K % NSET);
@@ -2473,7 +2478,8 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     double rows = 0;
     for (int i = 0; i < j.nseg; ++i) rows += 16.0 * (double)j.seg[i].nhalf;
     {
-    PnProfScope prof(6 + j.cfg, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone (not the slab reduction)
+    // (class per kernel instantiation: 6 + cfg; the Q24 forms of the 256 x 256 tile are 11 (Y in Q24) and 12 (X and Y in Q24))
+    PnProfScope prof((j.cfg == 0 && j.fmt) ? (j.fmt == 3 ? 12 : 11) : 6 + j.cfg, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone
     switch (j.cfg) {
         case 0:
             if constexpr (kQ24<NP>) {

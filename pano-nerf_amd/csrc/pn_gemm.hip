@@ -42,7 +42,7 @@ static int g_dbg = 0;
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_free_events;
-#define PN_PROF_CLASSES 12
+#define PN_PROF_CLASSES 14
 static double g_prof_ms[PN_PROF_CLASSES] = {0}, g_prof_flops[PN_PROF_CLASSES] = {0};
 static int64_t g_prof_n[PN_PROF_CLASSES] = {0};
 
