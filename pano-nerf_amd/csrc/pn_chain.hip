@@ -306,11 +306,13 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
     memcpy(dst, o, 16);
 }
 
-#ifdef PN_TRACE_CHAIN  // debug build only (PN_EXTRA=-DPN_TRACE_CHAIN): shader-clock stamps of one wave's second tile
+#if defined(PN_TRACE_CHAIN) || defined(PN_TRACE_WG)  // debug builds only (-DPN_TRACE_CHAIN / -DPN_TRACE_WG): shader-clock stamps
 __device__ unsigned long long g_chain_trace[64];
 extern "C" int pn_chain_trace_read(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
 }
+#endif
+#ifdef PN_TRACE_CHAIN
 #define TR(i)                                                                                          \
     do {                                                                                               \
         if (blockIdx.x == 0 && threadIdx.x == 0 && st == (int64_t)gridDim.x) g_chain_trace[i] = __builtin_amdgcn_s_memtime(); \
@@ -1901,6 +1903,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
 #ifndef PN_WG_Q24_NSET
 #define PN_WG_Q24_NSET 4
 #endif
+#ifndef PN_WG_Q24_ALT  // 1: the two waves of a SIMD take staging and products in opposite orders (see the loop)
+#define PN_WG_Q24_ALT 1
+#endif
 #ifndef PN_WG_Q24_STEADY  // 1: whole trips without a condition (see the loop); measured slower in the training step, off
 #define PN_WG_Q24_STEADY 0
 #endif
@@ -1908,6 +1913,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NSET = (X24 && LU == 1) ? PN_WG_Q24_NSET : ((NP <= 2 && (X24 ? 0 : LX) + (Y24 ? 0 : LY) + 3 * LU <= 4) ? 3 : 2);
     f32x4 xr[NSET][LX], yr[NSET][LY];
     f32x4 ur[NSET][LU > 0 ? LU : 1][3];  // a unit: 48 bytes
+    constexpr bool ALT = X24 && PN_WG_Q24_ALT;
+    // (Measured and dropped in the alternating loop: the two halves of the workgroup swapping the X units - whose row sums cost a
+    // wave ~500 cycles more per half block - with the parity of the half block: 828 us per launch with or without.)
+    auto unit_of = [&](int i) { return tid + NTH * i; };
     float bw[NSET] = {};  // bias weight of the half block held in each set
     // NP = 2: ONE unit for the whole job, 2^unit = the scale of every product in the accumulators: the smallest sx + sy over
     // the job's segments (the segment with the LARGEST products).  A segment whose own exponents add up to more is scaled
@@ -1982,7 +1991,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             const unsigned char* yq = reinterpret_cast<const unsigned char*>(cY) + blk * ((int64_t)cFY * 48);
 #pragma unroll
             for (int i = 0; i < LU; ++i) {
-                const int u = tid + NTH * i;
+                const int u = unit_of(i);
                 if ((UX + UY) % NTH == 0 || u < UX + UY) {
                     const f32x4* p = reinterpret_cast<const f32x4*>(u < UX ? xq + u * 48 : yq + (u - UX) * 48);  // (wave-uniform)
                     ur[set][i][0] = WG_LD(p);
@@ -2061,7 +2070,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
         if constexpr (X24 || Y24) {
 #pragma unroll
             for (int i = 0; i < LU; ++i) {
-                const int u = tid + NTH * i;
+                const int u = unit_of(i);
                 if ((UX + UY) % NTH == 0 || u < UX + UY) {
                     if (u < UX) put_unit(xs, PX, u, ur[set][i], sx[set], bsum4[i], bw[set]);  // (wave-uniform)
                     else put_unit(ys, PY, u - UX, ur[set][i], sy[set], nullptr, 0.f);
@@ -2114,16 +2123,90 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split32<NP>(af[i], bf, acc[i][j]);
         }
     };
+#ifdef PN_TRACE_WG  // debug build only: phase times of workgroup 0 (every wave), summed over its half blocks
+    unsigned long long tw[4] = {0, 0, 0, 0};
+#define WGT(i, expr)                                                   \
+    do {                                                               \
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();   \
+        expr;                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+        tw[i] += __builtin_amdgcn_s_memtime() - t0_;                   \
+    } while (0)
+#else
+#define WGT(i, expr) expr
+#endif
     // half block h + K of a trip: register set K % NSET, LDS buffer K % 2 (static indices)
     auto one = [&](auto kc, int64_t h) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value;
         if (h + K < h1) {  // (uniform)
-            stage(K % 2, K % NSET);
-            __syncthreads();
-            if (h + K + NSET < h1) load(h + K + NSET, K % NSET);
-            compute(K % 2);
+            WGT(0, stage(K % 2, K % NSET));
+            WGT(1, __syncthreads());
+            WGT(2, if (h + K + NSET < h1) load(h + K + NSET, K % NSET));
+            WGT(3, compute(K % 2));
         }
     };
+    if constexpr (ALT) {
+        // ALTERNATING ORDER.  In the common order (below) both waves of a SIMD stage, then both multiply; the phase trace
+        // (tools/trace_wgrad.py) showed the second-dispatched wave of every SIMD losing the arbitration for the matrix pipe,
+        // finishing its products last and only then starting to stage: the pipe idle for half of every half block.  Here wave
+        // type t (0: waves 0 .. NW/2 - 1, 1: their SIMD partners) runs   products(K) ; stage(K + 1 + t) ; refill   per half block
+        // K - ONE instruction sequence - with its barrier behind the products (t = 1) or behind the staging (t = 0): after a
+        // barrier one wave of a SIMD multiplies while its partner converts, then they swap.  The partner is one half block
+        // ahead in its staging (it staged half block 1 in the prologue), its LDS buffer index the only run-time difference; the
+        // register set of a staging is (K + 1) % NSET for both, the loads are unconditional (past the end: the last half block
+        // again, never staged) so that hipcc counts them.  Hazards: a wave stages into buffer b only behind a barrier that
+        // everyone passed after its products from b; products from b start behind a barrier everyone passed after staging b.
+        const int t = wid >= (WM * WN) / 2 ? 1 : 0;  // (wave-uniform)
+        const int64_t n = h1 - h0;
+        auto clampd = [&](int64_t hb) { return h0 + (hb < n ? hb : n - 1); };
+        if (n > 0) {
+            load(h0, 0);
+            stage(0, 0);
+            load(clampd(1), 0);          // (type 0 does not need it: issued by every wave so that hipcc's count of the loads in
+            if (t && 1 < n) stage(1, 0);  //  flight is the same on every path into the loop)
+#pragma unroll
+            for (int sidx = 1; sidx < NSET; ++sidx) load(clampd(sidx + t), sidx);
+            load(clampd(NSET + t), 0);
+            __syncthreads();
+            constexpr int TRIPA = NSET == 3 ? 6 : (NSET == 4 ? 4 : 2);
+            auto alt = [&](auto kc, auto guard, int64_t k0) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if (!decltype(guard)::value || k0 + K < n) {  // (uniform)
+                    WGT(3, compute(K % 2));
+                    if (t) WGT(1, __syncthreads());
+                    const int64_t hb = k0 + K + 1 + t;
+                    if (hb < n) WGT(0, stage((K + 1 + t) & 1, (K + 1) % NSET));
+                    WGT(2, load(clampd(hb + NSET), (K + 1) % NSET));
+                    if (!t) WGT(1, __syncthreads());
+                }
+            };
+            int64_t k0 = 0;
+            for (; k0 + TRIPA <= n; k0 += TRIPA) {  // whole trips: no condition around a half block (hipcc counts the loads)
+                alt(std::integral_constant<int, 0>{}, std::false_type{}, k0);
+                alt(std::integral_constant<int, 1>{}, std::false_type{}, k0);
+                if constexpr (TRIPA >= 4) {
+                    alt(std::integral_constant<int, 2>{}, std::false_type{}, k0);
+                    alt(std::integral_constant<int, 3>{}, std::false_type{}, k0);
+                }
+                if constexpr (TRIPA == 6) {
+                    alt(std::integral_constant<int, 4>{}, std::false_type{}, k0);
+                    alt(std::integral_constant<int, 5>{}, std::false_type{}, k0);
+                }
+            }
+            if (k0 < n) {  // the last, partial trip
+                alt(std::integral_constant<int, 0>{}, std::true_type{}, k0);
+                alt(std::integral_constant<int, 1>{}, std::true_type{}, k0);
+                if constexpr (TRIPA >= 4) {
+                    alt(std::integral_constant<int, 2>{}, std::true_type{}, k0);
+                    alt(std::integral_constant<int, 3>{}, std::true_type{}, k0);
+                }
+                if constexpr (TRIPA == 6) {
+                    alt(std::integral_constant<int, 4>{}, std::true_type{}, k0);
+                    alt(std::integral_constant<int, 5>{}, std::true_type{}, k0);
+                }
+            }
+        }
+    } else
     if (h0 < h1) {
 #pragma unroll
         for (int k = 0; k < NSET; ++k) {
@@ -2174,6 +2257,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
             }
         }
     }
+#ifdef PN_TRACE_WG
+    if (blockIdx.x == 0 && lane == 0 && (X24 && Y24)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g_chain_trace[8 * i + wid] = tw[i];
+        if (wid == 0) g_chain_trace[32] = (unsigned long long)(h1 - h0);
+    }
+#endif
     float* out = a.slab + (int64_t)blockIdx.x * a.slab_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
