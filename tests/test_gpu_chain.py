@@ -108,6 +108,15 @@ def test_chain_kernels_against_fp64_autograd(M, rows_per_ray, view_rows, nc, pla
         (raw_rgb64, raw_den64), enc64 = model64(mean.double())
     assert rel(t32_rows(enc_t, Mp, 96)[:M].cpu(), enc64.view(M, 96)) < 1e-5
     assert rel(rr.cpu(), raw_rgb64.view(M, 3)) < 3e-5 and rel(rd.cpu(), raw_den64.view(M, nc)) < 3e-5
+    # h0 straight from the weights: the stored activation tensor decodes (fp32 T layout, or Q24 - fp32 rounded to 16 significant
+    # bits, include/panonerf_hip.h - where pn_chain_q24_slots says so) to relu(W0 enc + b0)
+    h0_64 = torch.relu(enc64.view(M, 96) @ params["layers.0.0.weight"].double().T + params["layers.0.0.bias"].double())
+    q0 = bool(int(lib.pn_chain_q24_slots(planes, 0)) & 1)
+    h0_all = tl.slot_rows(lib, acts_t[:Mp * 256], Mp, 256, q0)
+    h0 = h0_all[:M]
+    assert rel(h0.cpu(), h0_64) < (2e-5 if q0 else 2e-6), (q0, rel(h0.cpu(), h0_64))
+    if q0:  # and exactly what the host-side encoder makes of the same fp32 values (byte order and rounding of the format)
+        assert bool((tl.q24_round(h0_all) == h0_all).all())
     h7 = t32_rows(acts_t[7 * Mp * 256:8 * Mp * 256], Mp, 256)[:M]
     gates = gates_of(ev, True)
     assert bool((gates[7] == (h7 > 0).cpu()).all())  # the recorded gate bits are the signs of the stored activations
