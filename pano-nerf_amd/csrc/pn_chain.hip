@@ -1913,7 +1913,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     constexpr int NSET = (X24 && LU == 1) ? PN_WG_Q24_NSET : ((NP <= 2 && (X24 ? 0 : LX) + (Y24 ? 0 : LY) + 3 * LU <= 4) ? 3 : 2);
     f32x4 xr[NSET][LX], yr[NSET][LY];
     f32x4 ur[NSET][LU > 0 ? LU : 1][3];  // a unit: 48 bytes
-    constexpr bool ALT = X24 && PN_WG_Q24_ALT;
+    // the 256 x 256 tile on Q24 operands (one or both) and on bf16 tensors: measured same box, us per launch in the training step,
+    // common -> alternating order: both in Q24 821 -> 783, Y in Q24 892 -> 832, bf16 tensors 426 -> 358; NOT on fp32 tensors with
+    // fp16 pairs (589 -> 644) or the six-product split (1230 -> 1258)
+    constexpr bool ALT = PN_WG_Q24_ALT && (WM * WN == 8 && TM == 2 && TN == 4) && (X24 || Y24 || NP == 1);
     // (Measured and dropped in the alternating loop: the two halves of the workgroup swapping the X units - whose row sums cost a
     // wave ~500 cycles more per half block - with the parity of the half block: 828 us per launch with or without.)
     auto unit_of = [&](int i) { return tid + NTH * i; };

@@ -1,0 +1,11 @@
+#!/bin/bash
+# the training step in the three fused modes on the default library and on every variant build, same box
+cd "$(dirname "$0")/.."
+for f in pano-nerf_amd/libpanonerf_hip.so pano-nerf_amd/libpanonerf_hip_*.so; do
+  [ -f $f ] || continue
+  for m in fused_f16x2 fused fused_bf16; do
+    echo "== $f $m"
+    PN_LIB=$f timeout -k 10 200 python3 tools/bench_with_lib.py --mlp-mode $m --no-cfg2 --no-cpu-baseline --no-inference --steps 10 --warmup 3 > /tmp/b.json 2>/tmp/b.err || tail -3 /tmp/b.err
+    python3 tools/show_bench.py /tmp/b.json 2>/dev/null | grep "rays/s\|2, 4, 4, 2"
+  done
+done
