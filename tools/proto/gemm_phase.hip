@@ -32,8 +32,10 @@ __global__ __launch_bounds__(512) void k_gemm_phase(const uint32_t* seed, float*
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < (SHAPE == 0 ? 4 : 16); ++e) acc[t][e] = 0.f;
-    const unsigned char* base = lds + lane * 16;
+    uint32_t off = lane * 16;
     for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(off));  // (opaque: the fragment reads are not loop-invariant to the compiler)
+        const unsigned char* base = lds + off;
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const f16x8 ah = *reinterpret_cast<const f16x8*>(base + (2 * s) * 1024);
