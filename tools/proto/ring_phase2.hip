@@ -1,0 +1,165 @@
+// MICROBENCHMARK (not part of the library): the hand-scheduled GEMM-phase loop (gemm_phase.hip, asm fragment reads 3 steps ahead: 91 % of the
+// matrix pipe with two waves per SIMD) WITH the chains' weight ring added piece by piece:
+//   MODE bit 0: s_barrier at every chunk hand-over (the look-ahead reaches the next chunk's first step: its acquire)
+//   MODE bit 1: LDS-DMA refill (5 slots of 24 KB, 3 x 1-KB buffer_load ... lds per wave and chunk, one behind every fourth step's MFMAs,
+//               counted vmcnt at the acquire; implies the barrier)
+//   MODE bit 2: a fourth, 256-B DMA instruction per chunk on waves 0-3 (the chains' bias KB)
+//   MODE bit 3: 64 dword stores per wave every 11 chunks (an epilogue's T stores), before the next chunk's acquire
+//   MODE bit 4: the same 64 stores one per step behind the MFMAs of the following 64 steps
+//   MODE bit 5: the same bytes as 16 x 16-byte stores (1 KB contiguous per wave instruction), as a burst
+//   MODE bit 6: the 64 stores of wave w in ITS OWN window of 16 steps (steps 16 w .. 16 w + 15 of the 132-step period), four per step:
+//               no two waves of the CU store at the same time
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int SLOT = 25 * 1024, NSLOT = 5, D = NSLOT - 1, LA = 3;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_ring2(const unsigned char* w, int nchunk, float* out, float* sink, int rounds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool DMA = MODE & 2, BAR = (MODE & 1) || DMA, AUX = MODE & 4, ST = MODE & 8, STS = MODE & 16, ST4 = MODE & 32, STW = MODE & 64;
+    constexpr int POL = (MODE >> 7) & 7;  // cache policy of the burst stores: 0 default, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 sc1 nt
+    for (int i = tid; i < NSLOT * SLOT / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(lds)[i] = 0x3c003c00u ^ ((uint32_t)i * 2654435761u & 0x03ff03ffu);
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, nchunk * SLOT, 0x00020000);
+    f16x8 bh, bl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bh[j] = (_Float16)(1.0f + 0.01f * (float)((lane + j) & 7));
+        bl[j] = (_Float16)(0.001f * (float)((lane * 3 + j) & 7));
+    }
+    f32x4 acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    int pf = 0, pslot = 0, cslot = 0, soff = 0;
+    unsigned char* dst = lds;
+    auto piece = [&](int i) {
+        const int f = wid + 8 * i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + f * 1024), 16, lane * 16, soff + f * 1024, 0, 0);
+    };
+    auto begin_round = [&]() {
+        soff = pf * SLOT;
+        dst = lds + pslot * SLOT;
+        pf = pf + 1 == nchunk ? 0 : pf + 1;
+        pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;
+    };
+    if constexpr (DMA) {
+        for (int d = 0; d < D; ++d) {
+            begin_round();
+            for (int i = 0; i < 3; ++i) piece(i);
+        }
+    }
+    constexpr int SHARE = 3;
+    auto acquire = [&]() -> uint32_t {
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SHARE * (D - 1)) : "memory");
+        if constexpr (BAR) __builtin_amdgcn_s_barrier();
+        if constexpr (DMA) begin_round();
+        const uint32_t p = lds0 + cslot * SLOT + lane * 16;
+        cslot = cslot + 1 == NSLOT ? 0 : cslot + 1;
+        return p;
+    };
+    f16x8 qh[LA + 1], ql[LA + 1];
+#define RD(slot, a, s)                                                                                               \
+    do {                                                                                                             \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qh[slot]) : "v"(a), "n"((2 * (s)) * 1024) : "memory");      \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ql[slot]) : "v"(a), "n"((2 * (s) + 1) * 1024) : "memory");  \
+    } while (0)
+    uint32_t cur = acquire();
+    RD(0, cur, 0); RD(1, cur, 1); RD(2, cur, 2);
+    float* sp = sink + ((size_t)blockIdx.x * 512 + tid);
+    for (int r = 0; r < rounds; ++r) {
+        uint32_t nxt = cur;
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            if (s + LA == 12) {
+                if constexpr (ST) {
+                    if (r % 11 == 10) {
+#pragma unroll
+                        for (int k = 0; k < 64; ++k) {
+                            float* q = sp + (size_t)k * 131072;
+                            const float v = acc[k % 12][k & 3];
+                            if constexpr (POL == 0) *q = v;
+                            else if constexpr (POL == 1) asm volatile("global_store_dword %0, %1, off nt" ::"v"(q), "v"(v) : "memory");
+                            else if constexpr (POL == 2) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(q), "v"(v) : "memory");
+                            else if constexpr (POL == 3) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+                            else if constexpr (POL == 4) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
+                            else asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(q), "v"(v) : "memory");
+                        }
+                    }
+                }
+                if constexpr (ST4) {
+                    if (r % 11 == 10) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(sink + ((size_t)k * 131072 + (size_t)blockIdx.x * 512 + tid) * 4) = acc[k % 12];
+                    }
+                }
+                nxt = acquire();
+            }
+            if (s + LA < 12) {
+                switch (s + LA) {
+#define C(n) case n: RD((s + LA) % (LA + 1), cur, n); break;
+                    C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11)
+#undef C
+                }
+            } else {
+                switch (s + LA - 12) {
+#define C(n) case n: RD((s + LA) % (LA + 1), nxt, n); break;
+                    C(0) C(1) C(2)
+#undef C
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(qh[s % (LA + 1)]), "+v"(ql[s % (LA + 1)]) : "n"(2 * LA) : "memory");
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[s % (LA + 1)], bh, acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s % (LA + 1)], bl, acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s % (LA + 1)], bh, acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STS) {
+                const int k = (r % 11) * 12 + s;  // step since the 11-chunk boundary
+                if (k < 64) {
+                    sp[(size_t)k * 131072] = acc[s][k & 3];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (STW) {
+                const int k = (r % 11) * 12 + s - 16 * wid;  // step inside this wave's window
+                if (k >= 0 && k < 16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sp[(size_t)(4 * k + q) * 131072] = acc[s][q];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (DMA) {
+                // the round opened by the LAST acquire is issued over the 12 steps that follow it (steps 9, 10, 11 of this chunk and 0 .. 8 of the next)
+                const int pos = (s + 3) % 12;  // steps since that acquire
+                if (pos % 4 == 0) piece(pos / 4);
+                if constexpr (AUX) {
+                    if (pos == 6 && wid < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + 24 * 1024 + wid * 256), 4, lane * 4, soff + 24 * 1024 + wid * 256, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rs += acc[t][e];
+    if (rs == 12345.678f) out[tid] = rs;
+}
+
+extern "C" int ring2_run(int mode, const unsigned char* w, int nchunk, float* out, float* sink, int blocks, int rounds, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CASE(M) case M: hipLaunchKernelGGL((k_ring2<M>), dim3(blocks), dim3(512), NSLOT * SLOT, s, w, nchunk, out, sink, rounds); break;
+    switch (mode) {
+        CASE(0) CASE(1) CASE(2) CASE(6) CASE(8) CASE(14) CASE(9) CASE(17) CASE(33) CASE(65) CASE(70) CASE(137) CASE(265) CASE(393) CASE(521) CASE(649)
+        default: return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

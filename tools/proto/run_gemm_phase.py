@@ -10,7 +10,8 @@ seed = torch.randint(0, 2 ** 31 - 1, (256,), dtype=torch.int32, device=dev)
 out = torch.zeros(512, device=dev)
 st = lambda: torch.cuda.current_stream().cuda_stream
 iters = 2000
-for shape, name, cyc in ((0, "16x16x32", 16), (1, "32x32x16", 32)):
+for shape, name, cyc in ((0, "16x16x32", 16), (1, "32x32x16", 32), (2, "16x16x32 reads a pass ahead", 16), (3, "32x32x16 reads a pass ahead", 32),
+                         (4, "16x16x32 asm reads 1 step ahead", 16), (5, "16x16x32 asm reads 3 steps ahead", 16), (6, "16x16x32 asm reads 5 steps ahead", 16)):
     for waves in (4, 8):
         call = lambda: lib.gemm_phase_run(shape, waves, seed.data_ptr(), out.data_ptr(), 256, iters, st())
         assert call() == 0
@@ -25,6 +26,6 @@ for shape, name, cyc in ((0, "16x16x32", 16), (1, "32x32x16", 32)):
         mfma_per_simd = iters * 12 * 3 * (waves // 4)
         for clk in (2.1,):
             busy = mfma_per_simd * cyc / (ms * 1e-3 * clk * 1e9)
-        flops = 256 * waves * iters * 12 * 3 * (2 * 16 * 16 * 32) * (1 if shape == 0 else 2)
+        flops = 256 * waves * iters * 12 * 3 * (2 * 16 * 16 * 32) * (2 if shape in (1, 3) else 1)
         print(f"{name}  {waves // 4} wave(s) per SIMD: {ms:7.3f} ms   {flops / ms / 1e9:7.1f} TF issued   matrix pipe busy {100 * busy:5.1f} % at 2.1 GHz "
               f"({ms * 1e-3 * 2.1e9 / (iters * 12):6.1f} cycles per step and SIMD)")
