@@ -98,6 +98,16 @@ __global__ __launch_bounds__(512) void k_ring2(const unsigned char* w, int nchun
                         for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(sink + ((size_t)k * 131072 + (size_t)blockIdx.x * 512 + tid) * 4) = acc[k % 12];
                     }
                 }
+                if constexpr (POL == 6) {  // 16 x 12-byte stores (768 B contiguous per wave instruction): the Q24 quad stores
+                    if (r % 11 == 10) {
+                        typedef float f32x3 __attribute__((ext_vector_type(3)));
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const f32x3 v{acc[k % 12][0], acc[k % 12][1], acc[k % 12][2]};
+                            *reinterpret_cast<f32x3*>(sink + ((size_t)k * 131072 + (size_t)blockIdx.x * 512 + tid) * 3) = v;
+                        }
+                    }
+                }
                 nxt = acquire();
             }
             if (s + LA < 12) {
@@ -158,7 +168,7 @@ extern "C" int ring2_run(int mode, const unsigned char* w, int nchunk, float* ou
     hipStream_t s = (hipStream_t)stream;
 #define CASE(M) case M: hipLaunchKernelGGL((k_ring2<M>), dim3(blocks), dim3(512), NSLOT * SLOT, s, w, nchunk, out, sink, rounds); break;
     switch (mode) {
-        CASE(0) CASE(1) CASE(2) CASE(6) CASE(8) CASE(14) CASE(9) CASE(17) CASE(33) CASE(65) CASE(70) CASE(137) CASE(265) CASE(393) CASE(521) CASE(649)
+        CASE(0) CASE(1) CASE(2) CASE(6) CASE(8) CASE(14) CASE(9) CASE(17) CASE(33) CASE(65) CASE(70) CASE(137) CASE(265) CASE(393) CASE(521) CASE(649) CASE(769)
         default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
