@@ -854,6 +854,9 @@ __device__ __forceinline__ Ex acc_to_b(const accv (&acc)[NT], BFrag<NP> (&b)[KB]
 // bytes, not the instruction count.  Nor their burstiness: handing a vector's 64 stores to the NEXT layer's GEMM, one per
 // step behind its MFMAs, left k_chain_dgrad<2> at 1.77 ms (1.79).  Non-temporal stores: forward 2.30 ms (2.36), dgrad 1.83
 // (1.78), tangent 1.70 (1.72), backward unchanged - not adopted.)
+#ifndef PN_T_NT
+#define PN_T_NT 1
+#endif
 template <int NT, typename TE>
 __device__ __forceinline__ void store_t(TE* base, const accv (&acc)[NT]) {
     if constexpr (PN_ABL_CHAIN & 16) return;  // (timing ablation: no T stores)
@@ -862,7 +865,11 @@ __device__ __forceinline__ void store_t(TE* base, const accv (&acc)[NT]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float x = AQ(acc, qb, i);
+#if PN_T_NT  // non-temporal like the Q24 stores (see store_q24): written once, read much later by one weight-gradient GEMM
+            __builtin_nontemporal_store((TE)x, base + (QB * qb + i) * TILE);
+#else
             base[(QB * qb + i) * TILE] = (TE)x;
+#endif
         }
 }
 
@@ -896,12 +903,22 @@ __device__ __forceinline__ u32x3 pack_q24(float x0, float x1, float x2, float x3
 }
 // byte offset of this lane's part of a Q24 block: quad block qb of the lane is at + qb * 768
 __device__ __forceinline__ int q24_lane(int c, int g) { return g * 192 + c * 12; }
+#ifndef PN_Q24_NT
+#define PN_Q24_NT 1
+#endif
 template <int NT>
 __device__ __forceinline__ void store_q24(unsigned char* base, const accv (&acc)[NT]) {
     if constexpr (PN_ABL_CHAIN & 16) return;
 #pragma unroll
     for (int qb = 0; qb < NT * ACCQ; ++qb)
+        // non-temporal: written once, read once by a weight-gradient GEMM much later (same box, training step: 22.58 -> 22.30 ms; forward
+        // 1771 -> 1744 us, backward 1714 -> 1682, and the 256 x 256 weight-gradient tile that reads them 794 -> 756: the stores no longer
+        // displace the packed weights and the other operand from L2.  -DPN_Q24_NT=0: plain stores)
+#if PN_Q24_NT
+        __builtin_nontemporal_store(pack_q24(AQ(acc, qb, 0), AQ(acc, qb, 1), AQ(acc, qb, 2), AQ(acc, qb, 3)), reinterpret_cast<u32x3*>(base + qb * 768));
+#else
         *reinterpret_cast<u32x3*>(base + qb * 768) = pack_q24(AQ(acc, qb, 0), AQ(acc, qb, 1), AQ(acc, qb, 2), AQ(acc, qb, 3));
+#endif
 }
 
 // ReLU gate bits of a lane, MW words (4 with TILE 32, 2 with TILE 16): element j of k-step ks of the lane's B operand is half
@@ -1513,7 +1530,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
                         if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = (TE)x[j];
                     }
                     if constexpr (Q7) {
-                        if (rq) *reinterpret_cast<u32x3*>(rq + (2 * ks + h) * 768) = pack_q24(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]);
+                        if (rq) {
+#if PN_Q24_NT
+                            __builtin_nontemporal_store(pack_q24(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]), reinterpret_cast<u32x3*>(rq + (2 * ks + h) * 768));
+#else
+                            *reinterpret_cast<u32x3*>(rq + (2 * ks + h) * 768) = pack_q24(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]);
+#endif
+                        }
                     }
                 }
                 split_into<NP>(x, bh[ks], bex);
