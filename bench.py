@@ -111,7 +111,7 @@ def main():
                     help="capture forward+loss+backward (and Adam when N=1) in one HIP graph and replay it per step; auto = up "
                          "to 2048 rays per GPU (eager fallback if capture fails); off: eager launches, per-launch HIP events "
                          "inside the timed region")
-    ap.add_argument("--mlp-mode", choices=("fused", "fused_f16x2", "fused_bf16", "layerwise"),
+    ap.add_argument("--mlp-mode", choices=("fused", "fused_f16x2", "fused_f16x2_t32", "fused_bf16", "layerwise"),
                     default=os.environ.get("PN_MLP_MODE", DEFAULT_MODE),
                     help="fused_f16x2 (default): on-chip MLP chains, fp16 pairs with power-of-two scaling, 3 partial products "
                          "(fp32-class accuracy); fused: the same kernels with the exact 3-term bf16 split, 6 partial products; "
@@ -121,7 +121,10 @@ def main():
                          "three-product kernels one chain is as fast as two at every size (512 rays: 136.0 k vs 132.7 k "
                          "rays/s, 1024: 151.4 k vs 153.1 k, 2048: 162.1 k vs 162.3 k)")
     ap.add_argument("--overlap", choices=("on", "off"), default="off",
-                    help="weight-gradient GEMMs on a side stream (on) or in line on the main stream (off)")
+                    help="weight-gradient GEMMs on a side stream beside the next evaluation's chains, each kernel family on its "
+                         "share of the CUs (on), or in line on the main stream, one batched job per layer (off)")
+    ap.add_argument("--chain-wgs", type=int, default=None, help="--overlap on: workgroups (CUs) of a chain kernel while weight gradients run beside it")
+    ap.add_argument("--wgrad-wgs", type=int, default=None, help="--overlap on: CUs of a weight-gradient job while a chain runs beside it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,9 +154,10 @@ def main():
     split = False  # (the layer-wise split GEMM mode of round 1 is gone: the fused chains supersede it)
     peak_nt = PEAK_F32_MFMA_TFLOPS
     fused = args.mlp_mode != "layerwise"
+    q24_on = args.mlp_mode == "fused_f16x2" and bool(int(_lib.load().pn_chain_q24_slots(2, 1, 0)))
     # fused chains on the 16-bit matrix cores (2.5 PF dense, bf16 and fp16 alike): six partial products per fp32-equivalent
     # product (bf16 three-term split), three (fp16 pair) or one (plain bf16)
-    np_ = {"fused": 3, "fused_f16x2": 2, "fused_bf16": 1}.get(args.mlp_mode, 3)  # template argument of the fused kernels
+    np_ = {"fused": 3, "fused_f16x2": 2, "fused_f16x2_t32": 2, "fused_bf16": 1}.get(args.mlp_mode, 3)  # template argument of the fused kernels
     peak_chain = PEAK_BF16_MFMA_TFLOPS / {3: 6.0, 2: 3.0, 1: 1.0}[np_]
     # names as rocprofv3 prints them (profiles/*_kernel_stats.csv, profiles/r02_pmc_summary.json)
     CLASSES = ((0, "k_gemm_nt"), (1, "k_gemm_tn"), (2, f"k_chain_fwd<{np_}>"), (3, f"k_chain_dgrad<{np_}>"),
@@ -200,6 +204,10 @@ def main():
                            mlp_num_density_channels=5, num_env_samples=10).to(dev)
     model.mlp_mode = args.mlp_mode
     model.overlap_weight_grads = args.overlap == "on"
+    if args.chain_wgs is not None:
+        model.overlap_chain_wgs = args.chain_wgs
+    if args.wgrad_wgs is not None:
+        model.overlap_wgrad_wgs = args.wgrad_wgs
     if world > 1:  # identical replicas
         dist.broadcast(model.mlp.flat_params(), 0)
     opt = pn.FlatAdam(model.mlp, lr=2e-4)
@@ -246,47 +254,59 @@ def main():
 
     def try_capture():
         """Whole-step capture: ~700 launches become one graph launch (the step is launch-latency sensitive at
-        512 rays per GPU).  Falls back to eager launches if capture is not possible."""
+        512 rays per GPU).  The decision to replay is COLLECTIVE: a capture that throws on one rank, or a replayed step that
+        does not reproduce an eager step on one rank, sends EVERY rank back to eager launches - every rank reaches the same
+        all-reduce of the verdict whatever happened locally (a rank that skipped it would pair its next collective, the
+        614 k-float gradient all-reduce, with the others' 1-float verdict)."""
         nonlocal graph
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
+        ok, why, check = True, None, None
+        try:
+            if os.environ.get("PN_BENCH_FAIL_CAPTURE_RANK") == str(rank):  # test hook (tests/test_gpu_bench_dist.py)
+                raise RuntimeError("forced capture failure on this rank (PN_BENCH_FAIL_CAPTURE_RANK)")
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    out = fwd_bwd()
+                    opt.step_dev(out[3], lr_dev, grad_scale=1.0 / world) if world == 1 else None
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's helper threads may touch HIP while we capture; they must not invalidate the capture
+            with torch.cuda.graph(g_, capture_error_mode="thread_local" if world > 1 else "global"):
                 out = fwd_bwd()
-                opt.step_dev(out[3], lr_dev, grad_scale=1.0 / world) if world == 1 else None
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g_ = torch.cuda.CUDAGraph()
-        # thread_local: RCCL's helper threads may touch HIP while we capture; they must not invalidate the capture
-        with torch.cuda.graph(g_, capture_error_mode="thread_local" if world > 1 else "global"):
-            out = fwd_bwd()
-            if world == 1:
-                opt.step_dev(out[3], lr_dev, grad_scale=1.0)
-        state["out"] = out
-        graph = g_
-        # Self-check (the first RCCL run captures with RCCL's helper threads alive): one replay must reproduce one eager
-        # step on the SAME batch - same generator state, hence the same rays and jitter - in loss and flat gradient.  A
-        # mismatch on ANY rank sends every rank back to eager launches (config.launch says so).
-        rng = torch.cuda.get_rng_state(dev)
-        l_e, _, _, g_e = fwd_bwd()
-        l_e, g_e = l_e.clone(), g_e.clone()
-        torch.cuda.set_rng_state(rng, dev)
-        graph.replay()
-        l_g, g_g = state["out"][0], state["out"][3]
-        torch.cuda.synchronize()
-        scale = float(g_e.abs().max())
-        ok = (bool(torch.isfinite(l_g)) and abs(float(l_g) - float(l_e)) <= 1e-6 * abs(float(l_e))
-              and float((g_g - g_e).abs().max()) <= 1e-6 * scale and scale > 0)
+                if world == 1:
+                    opt.step_dev(out[3], lr_dev, grad_scale=1.0)
+            state["out"] = out
+            # Self-check (the first RCCL run captures with RCCL's helper threads alive): one replay must reproduce one eager
+            # step on the SAME batch - same generator state, hence the same rays and jitter - in loss and flat gradient.
+            rng = torch.cuda.get_rng_state(dev)
+            l_e, _, _, g_e = fwd_bwd()
+            l_e, g_e = l_e.clone(), g_e.clone()
+            torch.cuda.set_rng_state(rng, dev)
+            g_.replay()
+            l_g, g_g = state["out"][0], state["out"][3]
+            torch.cuda.synchronize()
+            scale = float(g_e.abs().max())
+            ok = (bool(torch.isfinite(l_g)) and abs(float(l_g) - float(l_e)) <= 1e-6 * abs(float(l_e))
+                  and float((g_g - g_e).abs().max()) <= 1e-6 * scale and scale > 0)
+            check = {"loss_eager": float(l_e), "loss_replay": float(l_g),
+                     "max_grad_diff_over_max_grad": float((g_g - g_e).abs().max()) / max(scale, 1e-30)}
+            if not ok:
+                why = f"a replayed step does not reproduce the eager step ({check})"
+        except Exception as e:  # this rank cannot replay: the others must learn it through the verdict below
+            ok, why, g_ = False, f"graph capture unavailable ({type(e).__name__}: {e})", None
+            torch.cuda.synchronize()
         flag = torch.tensor([1.0 if ok else 0.0], device=dev)
         if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        state["replay_check"] = {"loss_eager": float(l_e), "loss_replay": float(l_g),
-                                 "max_grad_diff_over_max_grad": float((g_g - g_e).abs().max()) / max(scale, 1e-30),
-                                 "ok_all_ranks": bool(flag.item() > 0.5)}
-        if flag.item() < 0.5:
-            print(f"[bench] rank {rank}: a replayed step does not reproduce the eager step "
-                  f"({state['replay_check']}); running eagerly", file=sys.stderr)
-            graph = None
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # reached by every rank on every path
+        ok_all = bool(flag.item() > 0.5)
+        state["replay_check"] = dict(check or {}, ok_all_ranks=ok_all, ok_this_rank=ok, reason=why)
+        graph = g_ if ok_all else None
+        if not ok_all:
+            print(f"[bench] rank {rank}: {why or 'another rank cannot replay the step'}; every rank runs eagerly", file=sys.stderr)
+            if args.graph == "on" and not ok and not os.environ.get("PN_BENCH_FAIL_CAPTURE_RANK"):
+                raise RuntimeError(why)
 
     def fence():
         if world > 1:
@@ -302,14 +322,7 @@ def main():
     # memset -> accumulating kernel (profiles/r03_graph_memset_nodes.txt); the tables are cleared by a kernel now.)
     use_graph = args.graph == "on" or (args.graph == "auto" and nb <= 2048)
     if use_graph:
-        try:
-            try_capture()
-        except Exception as e:  # keep going with eager launches
-            if args.graph == "on":
-                raise
-            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
+        try_capture()  # (falls back to eager launches on every rank together; see there)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -423,7 +436,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": {"fused": "f32 (3xbf16 split products, fp32 accumulate)",
-                      "fused_f16x2": "f32 (2xfp16 split products, fp32 accumulate)",
+                      "fused_f16x2": "f32 (2xfp16 split products, fp32 accumulate; weight-gradient operands h_l / delta_l / r_l / hdot_l "
+                                     "stored with 16 significant bits, 'Q24')" if q24_on else
+                                     "f32 (2xfp16 split products, fp32 accumulate)",
+                      "fused_f16x2_t32": "f32 (2xfp16 split products, fp32 accumulate; every stored tensor fp32)",
                       "fused_bf16": "bf16 (fp32 accumulate)"}.get(args.mlp_mode, "f32"), "data": "synthetic",
             "config": {"workload": f"panonerf.yaml train step, synthetic {args.height}x{args.width} pano pool x3 cams, "
                                    f"{args.samples} coarse + {args.samples} fine samples, 10x10 env-light rays, "
@@ -432,7 +448,7 @@ def main():
                        "global_batch": args.global_batch, "rays_per_gpu": hi - lo, "num_samples": args.samples,
                        "parallelism": f"dp{world} (rays sharded, one 2.455 MB gradient all-reduce/step)",
                        "launch": ("hip-graph replay" if used_graph else
-                                  ("eager (a replayed step did not reproduce the eager step: fell back)"
+                                  ("eager (graph capture failed or a replayed step did not reproduce the eager step on some rank: every rank fell back)"
                                    if (state["replay_check"] and not state["replay_check"]["ok_all_ranks"]) else "eager")),
                        "replay_check": state["replay_check"],
                        "data_parallel_audit": audit,
@@ -445,7 +461,14 @@ def main():
                                                            "v_mfma_f32_*_bf16, fp32 accumulate (fp32 accuracy)",
                                                   "fused_f16x2": "x 2^e = h + l (fp16, |error| < 2^-24 |x|; one power-of-two "
                                                                  "scale per weight matrix and per sample or tensor), three "
-                                                                 "partial products on v_mfma_f32_*_f16, fp32 accumulate",
+                                                                 "partial products on v_mfma_f32_*_f16, fp32 accumulate"
+                                                                 + ("; the 256-wide tensors that only the weight-gradient GEMMs read "
+                                                                    "back (h0..h6, hdot0..6, delta_l and r_l for l = 1-4, 6, 7) are "
+                                                                    "STORED rounded to 16 significant bits, three bytes per element "
+                                                                    "(Q24): outputs are unaffected, weight gradients carry a 2^-17 "
+                                                                    "relative rounding per operand (mlp_mode fused_f16x2_t32 keeps "
+                                                                    "them fp32)" if q24_on else ""),
+                                                  "fused_f16x2_t32": "as fused_f16x2 with every stored tensor fp32 (no Q24)",
                                                   "fused_bf16": "plain bf16 operands on v_mfma_f32_*_bf16, fp32 accumulate"
                                                   }.get(args.mlp_mode, ""))
                                     if fused else
@@ -470,7 +493,7 @@ def main():
                                   "for the bf16 three-term split, three for the fp16 pair) against the dense 16-bit MFMA peak "
                                   "(2.5 PF); `mfma.algorithmic_tflops` is the fp32-equivalent rate; `hbm` is the same kernel's "
                                   "algorithmic operand bytes against 8 TB/s; `other[*].tflops` are fp32-equivalent"
-                                  if args.mlp_mode in ("fused", "fused_f16x2") else
+                                  if args.mlp_mode in ("fused", "fused_f16x2", "fused_f16x2_t32") else
                                   ("`peak` is the dense bf16 MFMA figure (2.5 PF)" if args.mlp_mode == "fused_bf16" else
                                    "`peak` is the 2.4 GHz datasheet figure; under the power cap the same k_gemm_nt binary runs "
                                    "126 TF on zero/constant operands and 101 TF on N(0,1) operands (tools/bench_clock.py, "

@@ -200,7 +200,16 @@ int pn_chain_tile(void);
  * fp32 - a quarter of the step's HBM traffic in these tensors; each keeps its slot's address (slot * Mp * 256 floats) and uses the
  * first three quarters of it.  Bit s of the result: slot s of the tensor is Q24; tensor 0: activations h_s (acts_t), 1: tangents
  * hdot_s (tang_t), 2: deltas (delta_t), 3: reverse-sweep vectors r_s (rs_t).  0 for every other mode: all fp32 (or bf16). */
-int pn_chain_q24_slots(int planes, int tensor);
+int pn_chain_q24_slots(int planes, int t_format, int tensor);
+/* Two arguments every chain entry point below takes (ABI 2):
+ *   t_format  0: every T tensor fp32 (bf16 with planes = 1); 1: Q24 where pn_chain_q24_slots says so (planes = 2 only).  The calls of
+ *             one evaluation - forward, sweeps, backward, weight gradients - must agree on it: it is the layout of what they exchange.
+ *   max_wgs   0: the launch sizes its persistent grid to every CU of the device.  > 0: it occupies at most that many workgroups (a chain
+ *             workgroup or a 256-wide weight-gradient workgroup fills a CU), so that a kernel of the OTHER family, launched on another
+ *             stream with the complementary budget, finds the remaining CUs free: the chains are bound by matrix-instruction issue and
+ *             their stores (2.7 TB/s of HBM traffic), the weight gradients by their operand reads - side by side on disjoint CUs each
+ *             sees less HBM contention than alone on the whole chip.  Results do not depend on it for the
+ *             chains; for pn_chain_wgrad it moves the split points of the sum over samples (deterministic for a given value). */
 int64_t pn_chain_pack_bytes(int planes);
 int pn_chain_pack(const float* params, int num_density_channels, int planes, void* pack, void* stream);
 /* floats of acts_t: h0..h7 [256] x 8, bottleneck | view encoding [288], view hidden [128].  acts_t may be NULL in
@@ -215,19 +224,19 @@ int pn_chain_amax_slots(void);
 int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int num_density_channels, int planes,
                      const void* pack, const float* mean, const float* cov, const float* viewdirs, float* view_tab,
                      float* enc_t, float* acts_t, uint32_t* masks, float* raw_rgb /*[M,3]*/, float* raw_density /*[M,nc]*/,
-                     uint32_t* amax, void* stream);
+                     uint32_t* amax, int t_format, int max_wgs, void* stream);
 /* vmap(jacrev(compute_graph))[1] (models/pano_mip_nerf.py:299-303) as one reverse sweep.  keep_all != 0: rs_t is
  * T [8][Mp*256] and receives r_0..r_7 (the second-order weight gradients need them); keep_all = 0 (inference): rs_t is ONE
  * slot T [Mp*256], used only for the kernel's own reload of r_5. */
 int pn_chain_density_grad(int64_t M, int num_density_channels, int planes, float density_bias, const float* params,
                           const void* pack, const float* mean, const float* cov, const uint32_t* masks,
                           const float* raw_density, float* rs_t, int keep_all, float* grad_mean /*[M,3]*/,
-                          uint32_t* amax, void* stream);
+                          uint32_t* amax, int t_format, int max_wgs, void* stream);
 /* forward-mode tangent sweep along v_gradmean (the double backward of the normals block) */
 int pn_chain_tangent(int64_t M, int num_density_channels, int planes, const float* params, const void* pack,
                      const float* mean, const float* cov, const uint32_t* masks, const float* v_gradmean,
                      float* edot_t /*T [Mp*96]*/, float* tang_t /*T [8][Mp*256]*/, float* sdot /*[M]*/, uint32_t* amax,
-                     void* stream);
+                     int t_format, int max_wgs, void* stream);
 /* data-gradient chain.  drgb_t T [Mp*32], d8_t T [Mp*288], coef_t T [Mp*32]: with pn_chain_tile() = 32 the caller
  * zero-fills them once (the kernel writes 16 of their 32 padded features); with the default 16 the kernel writes them
  * whole.  sdot / coef_t: second-order path (both or neither); d_mean nullable. */
@@ -235,7 +244,7 @@ int pn_chain_backward(int64_t M, int num_density_channels, int planes, float den
                       const uint32_t* masks, const float* raw_density, const float* d_raw_rgb,
                       const float* d_raw_density, const float* sdot, const float* mean, const float* cov,
                       float* drgb_t, float* dhv_t /*T [Mp*128]*/, float* d8_t, float* delta_t /*T [8][Mp*256]*/,
-                      float* coef_t, float* d_mean /*[M,3]*/, uint32_t* amax, void* stream);
+                      float* coef_t, float* d_mean /*[M,3]*/, uint32_t* amax, int t_format, int max_wgs, void* stream);
 /* one evaluation's tensors for the weight gradients (host struct of device pointers) */
 typedef struct PnChainEval {
     int64_t M;
@@ -252,8 +261,12 @@ typedef struct PnChainEval {
     const uint32_t* amax; /* planes = 2: the evaluation's table of maxima; NULL otherwise */
 } PnChainEval;
 int64_t pn_chain_wgrad_work_floats(void);
+/* which: bit 1 = the second-order TRUNK rows (r_l^T hdot_{l-1}, r_0^T edot) of the evaluations that carry rs_t - their operands exist as
+ * soon as the tangent sweep has run, before the evaluation's backward chain, so a caller can reduce them under that chain on another
+ * stream; bit 0 = everything else (delta_l^T h_{l-1}, heads incl. the softplus' row against hdot_7, view / colour layer, bias gradients).
+ * grads is accumulated into (+=) by the job reductions, in launch order: concurrent calls on the same `grads` must share a stream. */
 int pn_chain_wgrad(int n_evals, const PnChainEval* evals_host, int num_density_channels, int planes, float* grads,
-                   float* work, int64_t work_floats, void* stream);
+                   float* work, int64_t work_floats, int which, int t_format, int max_wgs, void* stream);
 
 /* ---- volumetric rendering ---------------------------------------------------------
  * compute_graph activations (models/pano_mip_nerf.py:273-278) + volumetric_rendering

@@ -52,13 +52,13 @@ SIGNATURES = {
     "pn_chain_pack": ("i", "piipp"),
     "pn_chain_acts_floats": ("l", "l"),
     "pn_chain_amax_slots": ("i", ""),
-    "pn_chain_forward": ("i", "lilii" + "p" * 11 + "p"),
-    "pn_chain_density_grad": ("i", "liif" + "p" * 7 + "ippp"),
-    "pn_chain_tangent": ("i", "lii" + "p" * 10 + "p"),
-    "pn_chain_backward": ("i", "liif" + "p" * 15 + "p"),
+    "pn_chain_forward": ("i", "lilii" + "p" * 11 + "iip"),
+    "pn_chain_density_grad": ("i", "liif" + "p" * 7 + "ippiip"),
+    "pn_chain_tangent": ("i", "lii" + "p" * 10 + "iip"),
+    "pn_chain_backward": ("i", "liif" + "p" * 15 + "iip"),
     "pn_chain_wgrad_work_floats": ("l", ""),
-    "pn_chain_q24_slots": ("i", "ii"),
-    "pn_chain_wgrad": ("i", "ipiipplp"),
+    "pn_chain_q24_slots": ("i", "iii"),
+    "pn_chain_wgrad": ("i", "ipiippliiip"),
     "pn_mfma_probe": ("i", "piip"),
     "pn_prof_enable": ("i", "i"),
     "pn_prof_read": ("i", "ippp"),

@@ -1264,6 +1264,7 @@ struct FwdArgs {
     uint32_t* masks;       // [9][Mp][8]
     float* raw_rgb;        // [M,3]
     float* raw_den;        // [M,nc]
+    int q24;               // NP = 2, 16-sample tiles: h0..h6 in Q24 (see pack_q24); 0: every T tensor fp32
 };
 __host__ __device__ constexpr int64_t act_off(int slot, int64_t Mp) {  // float offset of activation slot in acts_t
     return slot <= 8 ? (int64_t)slot * Mp * 256 : 8 * Mp * 256 + Mp * 288;
@@ -1325,7 +1326,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_fwd(FwdArgs 
         }
         auto finish_hidden = [&](int slot) {  // ReLU, T store, next B operand, gate bits
             relu<NT_H>(acc);
-            if (TP(a.acts_t)) store_vec<NP, NT_H>(TP(a.acts_t) + act_off(slot, Mp), T, 256, q24_act(slot), acc);  // (uniform)
+            if (TP(a.acts_t)) store_vec<NP, NT_H>(TP(a.acts_t) + act_off(slot, Mp), T, 256, a.q24 && q24_act(slot), acc);  // (uniform)
             const Ex e = acc_to_b<NP, NT_H, KS_H>(acc, bh);
             gate_words<NP, KS_H, KS_H>(bh, mw);
             store_gate(a.masks, slot, Mp, T.blk * TILE + T.c, T.g, mw);
@@ -1462,6 +1463,7 @@ struct SweepArgs {
     float* edot_t;               // T [96] (tangent sweep)
     float* out3;                 // [M,3] grad_mean (reverse sweep)
     float* sdot;                 // [M] (tangent sweep)
+    int q24;                     // r_l / hdot_l in Q24 where q24_delta / q24_act say so; 0: fp32
 };
 
 template <int NP>
@@ -1499,7 +1501,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
             else return 0;
         };
         {  // seed r_7
-            constexpr bool Q7 = kQ24<NP> && q24_delta(7);  // r_7 in three bytes per element: a quad block is one store
+            const bool Q7 = kQ24<NP> && a.q24 && q24_delta(7);  // r_7 in three bytes per element: a quad block is one store (uniform)
             TE* rt = (a.keep_all && !Q7) ? TP(a.vec_t) + (int64_t)7 * Mp * 256 + T.blk * (256 * TILE) + T.lo : nullptr;
             unsigned char* rq = (a.keep_all && Q7) ? reinterpret_cast<unsigned char*>(TP(a.vec_t) + (int64_t)7 * Mp * 256) +
                                                          T.blk * (int64_t)(256 * TILE * 3) + q24_lane(T.c, T.g)
@@ -1529,7 +1531,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
                         x[j] = bit ? sgm * wv[i] : 0.f;
                         if (rt) rt[(QB * (2 * ks + h) + i) * TILE] = (TE)x[j];
                     }
-                    if constexpr (Q7) {
+                    if constexpr (kQ24<NP>) {
                         if (rq) {
 #if PN_Q24_NT
                             __builtin_nontemporal_store(pack_q24(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]), reinterpret_cast<u32x3*>(rq + (2 * ks + h) * 768));
@@ -1547,7 +1549,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_dgrad(SweepA
         for (int l = 7; l >= 1; --l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
             TE* dst = a.keep_all ? TP(a.vec_t) + (int64_t)(l - 1) * Mp * 256 : (l - 1 == 5 ? TP(a.vec_t) : nullptr);
-            const Ex e = finish_gated<NP>(acc, pop_front(mk), dst, T, q24_delta(l - 1), bh);  // (r_5, re-read below, is never Q24)
+            const Ex e = finish_gated<NP>(acc, pop_front(mk), dst, T, a.q24 && q24_delta(l - 1), bh);  // (r_5, re-read below, is never Q24)
             bex = e.ex;
             RM.upd(l - 1, e.top);
         }
@@ -1616,13 +1618,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
             RM.upd(8, e.top);
             chain_gemm<NP, KS_ENC, NT_H, false, true>(R, benc, acc, lane, wx(F_L0) + bex);
         }
-        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t), T, q24_act(0), bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t), T, a.q24 && q24_act(0), bh);
         bex = e.ex;
         RM.upd(0, e.top);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L0 + l) + bex);
-            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)l * Mp * 256, T, q24_act(l), bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)l * Mp * 256, T, a.q24 && q24_act(l), bh);
             bex = e.ex;
             RM.upd(l, e.top);
         }
@@ -1631,12 +1633,12 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_tangent(Swee
             BFrag<NP> benc[KS_ENC];
             const int eex = reload_b<NP, KS_ENC>(et, benc, EXP_CAP_Z);
             chain_gemm<NP, KS_ENC, NT_H, false, false>(R, benc, acc, lane, wx(F_L5E) + eex);
-            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)5 * Mp * 256, T, q24_act(5), bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)5 * Mp * 256, T, a.q24 && q24_act(5), bh);
             bex = e.ex;
             RM.upd(5, e.top);
         }
         chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L6) + bex);
-        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)6 * Mp * 256, T, q24_act(6), bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.vec_t) + (int64_t)6 * Mp * 256, T, a.q24 && q24_act(6), bh);
         bex = e.ex;
         RM.upd(6, e.top);
         chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(F_L7) + bex);
@@ -1682,6 +1684,7 @@ struct BwdArgs {
     float* delta_t;             // T [8][256]
     float* coef_t;              // T [32] or null: row 0 = softplus'(z) (second-order dWd[0] term)
     float* d_mean;              // [M,3] or null
+    int q24;                    // delta_l in Q24 where q24_delta says so; 0: fp32
 };
 
 template <int NP>
@@ -1782,13 +1785,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void k_chain_bwd(BwdArgs 
         }
         BFrag<NP> bh[KS_H];
         chain_gemm<NP, KS_H + 1, NT_H, false, true>(R, be, acc, lane, wx(B_EXTRA) + bex);
-        e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)7 * Mp * 256, T, q24_delta(7), bh);
+        e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)7 * Mp * 256, T, a.q24 && q24_delta(7), bh);
         bex = e.ex;
         RM.upd(7, e.top);
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
             chain_gemm<NP, KS_H, NT_H, false, true>(R, bh, acc, lane, wx(B_L7 + 7 - l) + bex);
-            e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)(l - 1) * Mp * 256, T, q24_delta(l - 1), bh);
+            e = finish_gated<NP>(acc, pop_front(mk), TP(a.delta_t) + (int64_t)(l - 1) * Mp * 256, T, a.q24 && q24_delta(l - 1), bh);
             bex = e.ex;
             RM.upd(l - 1, e.top);
         }
@@ -2449,7 +2452,7 @@ struct AttrDone {
     bool done[PN_MAX_DEVICES];
 };
 template <typename K, typename A>
-static int launch_chain(K kernel, int lds_bytes, AttrDone& attr, int64_t nst, const A& a, hipStream_t s, int cls, double flops);
+static int launch_chain(K kernel, int lds_bytes, AttrDone& attr, int64_t nst, int max_wgs, const A& a, hipStream_t s, int cls, double flops);
 
 static int g_chain_cus[PN_MAX_DEVICES] = {};
 static int chain_cus() {
@@ -2460,8 +2463,11 @@ static int chain_cus() {
     }
     return g_chain_cus[dev];
 }
-static int chain_grid(int64_t nst) {
+// max_wgs > 0: the launch may occupy at most that many workgroups (= CUs: a chain workgroup fills one), so that a kernel of the
+// other family - the weight-gradient GEMMs, on another stream - finds the remaining CUs free (see pn_chain_wgrad)
+static int chain_grid(int64_t nst, int max_wgs) {
     int64_t wgs = (int64_t)chain_cus() * CH_WG_PER_CU;
+    if (max_wgs > 0 && max_wgs < wgs) wgs = max_wgs;
 #ifdef PN_TRACE_CHAIN  // diagnostic: PN_TRACE_ONE_WG=1 leaves every SIMD with ONE wave (is a GEMM phase slowed by its neighbour?)
     if (getenv("PN_TRACE_ONE_WG")) wgs = chain_cus();
 #endif
@@ -2469,7 +2475,7 @@ static int chain_grid(int64_t nst) {
 }
 
 template <typename K, typename A>
-static int launch_chain(K kernel, int lds_bytes, AttrDone& attr, int64_t nst, const A& a, hipStream_t s, int cls, double flops) {
+static int launch_chain(K kernel, int lds_bytes, AttrDone& attr, int64_t nst, int max_wgs, const A& a, hipStream_t s, int cls, double flops) {
     PnProfScope prof(cls, flops, s);
     const int dev = current_device();
     if (!attr.done[dev]) {  // (two threads racing here both set the same value)
@@ -2477,17 +2483,17 @@ static int launch_chain(K kernel, int lds_bytes, AttrDone& attr, int64_t nst, co
             return PN_ERR_HIP;
         attr.done[dev] = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(chain_grid(nst)), dim3(CH_THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL(kernel, dim3(chain_grid(nst, max_wgs)), dim3(CH_THREADS), lds_bytes, s, a);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
-#define LAUNCH_CHAIN(KERNEL, planes, nst, args, s, cls, flops)                                                   \
-    do {                                                                                                        \
-        static AttrDone done3 = {}, done2 = {}, done1 = {};                                                     \
-        if ((planes) == 3) return launch_chain(KERNEL<3>, Cfg<3>::LDS_BYTES, done3, nst, args, s, cls, flops);  \
-        if ((planes) == 2) return launch_chain(KERNEL<2>, Cfg<2>::LDS_BYTES, done2, nst, args, s, cls, flops);  \
-        if ((planes) == 1) return launch_chain(KERNEL<1>, Cfg<1>::LDS_BYTES, done1, nst, args, s, cls, flops);  \
-        return PN_ERR_UNSUPPORTED;                                                                              \
+#define LAUNCH_CHAIN(KERNEL, planes, nst, wgs, args, s, cls, flops)                                                   \
+    do {                                                                                                             \
+        static AttrDone done3 = {}, done2 = {}, done1 = {};                                                          \
+        if ((planes) == 3) return launch_chain(KERNEL<3>, Cfg<3>::LDS_BYTES, done3, nst, wgs, args, s, cls, flops);  \
+        if ((planes) == 2) return launch_chain(KERNEL<2>, Cfg<2>::LDS_BYTES, done2, nst, wgs, args, s, cls, flops);  \
+        if ((planes) == 1) return launch_chain(KERNEL<1>, Cfg<1>::LDS_BYTES, done1, nst, wgs, args, s, cls, flops);  \
+        return PN_ERR_UNSUPPORTED;                                                                                   \
     } while (0)
 // where the pieces of a packed blob are, per arithmetic mode
 struct ChainGeom {
@@ -2566,7 +2572,7 @@ __global__ __launch_bounds__(256) void k_reduce_job(const float* slabs, int64_t 
 }
 
 template <int NP>
-static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipStream_t s) {
+static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, int max_wgs, hipStream_t s) {
     WgArgs a{};
     int64_t total = 0;
     for (int i = 0; i < j.nseg; ++i) {
@@ -2581,6 +2587,7 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     // 37 / 20 KB): more sample ranges in flight, their staging and product phases interleave
     static const int kPerCu[5] = {1, 1, 1, 3, 4};
     int cus = chain_cus();
+    if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;  // the CUs this job may occupy (the rest run a chain kernel of another stream)
     int64_t nsplit = (int64_t)cus * kPerCu[j.cfg];
     if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;  // at least four half blocks per workgroup
     if (nsplit < 1) nsplit = 1;
@@ -2621,13 +2628,17 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, hipSt
     return PN_OK;
 }
 
+// T-tensor format of a call: 0 = every tensor fp32 (bf16 with planes = 1), 1 = Q24 where pn_chain_q24_slots says so (fp16 pairs with
+// 16-sample tiles only)
+static bool tfmt_ok(int planes, int t_format) { return t_format == 0 || (t_format == 1 && planes == 2 && kQ24<2>); }
+
 extern "C" {
 
 /* samples per T-layout block (= samples per wave of the chain kernels): 16 or 32 */
 int pn_chain_tile(void) { return TILE; }
 
-int pn_chain_q24_slots(int planes, int tensor) {
-    if (planes != 2 || !kQ24<2> || tensor < 0 || tensor > 3) return 0;
+int pn_chain_q24_slots(int planes, int t_format, int tensor) {
+    if (planes != 2 || t_format != 1 || !kQ24<2> || tensor < 0 || tensor > 3) return 0;
     int m = 0;
     for (int sl = 0; sl < 8; ++sl)
         if (tensor < 2 ? q24_act(sl) : q24_delta(sl)) m |= 1 << sl;
@@ -2658,8 +2669,9 @@ int pn_chain_amax_slots(void) { return AM_COUNT; }
 
 int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int planes, const void* pack,
                      const float* mean, const float* cov, const float* viewdirs, float* view_tab, float* enc_t, float* acts_t,
-                     uint32_t* masks, float* raw_rgb, float* raw_den, uint32_t* amax, void* stream) {
-    if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0) return PN_ERR_BAD_SHAPE;
+                     uint32_t* masks, float* raw_rgb, float* raw_den, uint32_t* amax, int t_format, int max_wgs, void* stream) {
+    if (M <= 0 || rows_per_ray <= 0 || view_rows <= 0 || max_wgs < 0) return PN_ERR_BAD_SHAPE;
+    if (!tfmt_ok(planes, t_format)) return PN_ERR_UNSUPPORTED;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     if (!pack || !mean || !cov || !viewdirs || !view_tab || !enc_t || !masks || !raw_rgb || !raw_den) return PN_ERR_NULL;  // acts_t may be null
     FwdArgs a{};
@@ -2678,19 +2690,21 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     PN_CHECK_LAUNCH();
     a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
     a.amax = planes == 2 ? amax : nullptr;
+    a.q24 = t_format;
     if (a.amax) {
         const int rc = chain_clear(a.amax, AM_COUNT, (hipStream_t)stream);
         if (rc != PN_OK) return rc;
     }
-    LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, a, (hipStream_t)stream, 2, (double)M * flops_mlp(nc));
+    LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, max_wgs, a, (hipStream_t)stream, 2, (double)M * flops_mlp(nc));
 }
 
 /* d sigma / d mean by one reverse sweep (see k_chain_dgrad).  rs_t: T32 [8][Mp*256] (r_0..r_7, kept for the second-order
  * weight gradients); grad_mean [M,3] = + d sigma / d mean. */
 int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, const float* params, const void* pack,
                           const float* mean, const float* cov, const uint32_t* masks, const float* raw_den, float* rs_t,
-                          int keep_all, float* grad_mean, uint32_t* amax, void* stream) {
-    if (M <= 0) return PN_ERR_BAD_SHAPE;
+                          int keep_all, float* grad_mean, uint32_t* amax, int t_format, int max_wgs, void* stream) {
+    if (M <= 0 || max_wgs < 0) return PN_ERR_BAD_SHAPE;
+    if (!tfmt_ok(planes, t_format)) return PN_ERR_UNSUPPORTED;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     ChainGeom g;
     if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
@@ -2707,14 +2721,16 @@ int pn_chain_density_grad(int64_t M, int nc, int planes, float density_bias, con
     a.wd0 = params + pn_layout(nc).wd;
     a.vec_t = rs_t; a.out3 = grad_mean; a.keep_all = keep_all != 0;
     a.amax = planes == 2 ? amax : nullptr;
-    LAUNCH_CHAIN(k_chain_dgrad, planes, a.nst, a, (hipStream_t)stream, 3, (double)M * kFlopsSweep);
+    a.q24 = t_format;
+    LAUNCH_CHAIN(k_chain_dgrad, planes, a.nst, max_wgs, a, (hipStream_t)stream, 3, (double)M * kFlopsSweep);
 }
 
 /* forward-mode tangent sweep along v (see k_chain_tangent): edot_t T32 [Mp*96], tang_t T32 [8][Mp*256], sdot [M]. */
 int pn_chain_tangent(int64_t M, int nc, int planes, const float* params, const void* pack, const float* mean,
                      const float* cov, const uint32_t* masks, const float* v, float* edot_t, float* tang_t, float* sdot,
-                     uint32_t* amax, void* stream) {
-    if (M <= 0) return PN_ERR_BAD_SHAPE;
+                     uint32_t* amax, int t_format, int max_wgs, void* stream) {
+    if (M <= 0 || max_wgs < 0) return PN_ERR_BAD_SHAPE;
+    if (!tfmt_ok(planes, t_format)) return PN_ERR_UNSUPPORTED;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     ChainGeom g;
     if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
@@ -2730,15 +2746,17 @@ int pn_chain_tangent(int64_t M, int nc, int planes, const float* params, const v
     a.wd0 = params + pn_layout(nc).wd;
     a.vec_t = tang_t; a.edot_t = edot_t; a.sdot = sdot;
     a.amax = planes == 2 ? amax : nullptr;
-    LAUNCH_CHAIN(k_chain_tangent, planes, a.nst, a, (hipStream_t)stream, 4, (double)M * kFlopsSweep);
+    a.q24 = t_format;
+    LAUNCH_CHAIN(k_chain_tangent, planes, a.nst, max_wgs, a, (hipStream_t)stream, 4, (double)M * kFlopsSweep);
 }
 
 /* backward chain (see k_chain_bwd).  sdot / coef_t: second-order path (both or neither); d_mean nullable. */
 int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const void* pack, const uint32_t* masks,
                       const float* raw_den, const float* d_raw_rgb, const float* d_raw_den, const float* sdot,
                       const float* mean, const float* cov, float* drgb_t, float* dhv_t, float* d8_t, float* delta_t,
-                      float* coef_t, float* d_mean, uint32_t* amax, void* stream) {
-    if (M <= 0) return PN_ERR_BAD_SHAPE;
+                      float* coef_t, float* d_mean, uint32_t* amax, int t_format, int max_wgs, void* stream) {
+    if (M <= 0 || max_wgs < 0) return PN_ERR_BAD_SHAPE;
+    if (!tfmt_ok(planes, t_format)) return PN_ERR_UNSUPPORTED;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     ChainGeom g;
     if (!chain_geom(planes, g)) return PN_ERR_UNSUPPORTED;
@@ -2757,7 +2775,8 @@ int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const v
     a.mean = mean; a.cov = cov;
     a.drgb_t = drgb_t; a.dhv_t = dhv_t; a.d8_t = d8_t; a.delta_t = delta_t; a.coef_t = coef_t; a.d_mean = d_mean;
     a.amax = planes == 2 ? amax : nullptr;
-    LAUNCH_CHAIN(k_chain_bwd, planes, a.nst, a, (hipStream_t)stream, 5, (double)M * (flops_mlp(nc) - (d_mean ? 0.0 : 2.0 * 2 * 96 * 256)));
+    a.q24 = t_format;
+    LAUNCH_CHAIN(k_chain_bwd, planes, a.nst, max_wgs, a, (hipStream_t)stream, 5, (double)M * (flops_mlp(nc) - (d_mean ? 0.0 : 2.0 * 2 * 96 * 256)));
 }
 
 
@@ -2770,8 +2789,10 @@ int64_t pn_chain_wgrad_work_floats(void) {
  * (or plain bf16) TN GEMM per layer over the sample blocks of all `n` evaluations (and, for an evaluation with
  * rs_t / tang_t, its second-order rows r_l^T hdot_{l-1}); accumulates (+=) into the flat gradient block. */
 int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grads, float* work, int64_t work_floats,
-                   void* stream) {
-    if (n < 1 || n > 3) return PN_ERR_BAD_SHAPE;
+                   int which, int t_format, int max_wgs, void* stream) {
+    if (n < 1 || n > 3 || which < 1 || which > 3 || max_wgs < 0) return PN_ERR_BAD_SHAPE;
+    if (!tfmt_ok(planes, t_format)) return PN_ERR_UNSUPPORTED;
+    const bool first = which & 1, second = which & 2;
     if (nc != 1 && nc != 5) return PN_ERR_UNSUPPORTED;
     if (planes != 1 && planes != 2 && planes != 3) return PN_ERR_UNSUPPORTED;
     if (!ev || !grads || !work) return PN_ERR_NULL;
@@ -2779,20 +2800,23 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     const PnLayout L = pn_layout(nc);
     int n2 = 0;
     for (int e = 0; e < n; ++e) {
-        if (ev[e].M <= 0 || !ev[e].enc_t || !ev[e].acts_t || !ev[e].drgb_t || !ev[e].dhv_t || !ev[e].d8_t || !ev[e].delta_t)
-            return PN_ERR_NULL;
+        if (ev[e].M <= 0 || !ev[e].enc_t || !ev[e].acts_t) return PN_ERR_NULL;
+        if (first && (!ev[e].drgb_t || !ev[e].dhv_t || !ev[e].d8_t || !ev[e].delta_t)) return PN_ERR_NULL;  // (written by the backward chain)
         if (ev[e].rs_t) {
-            if (!ev[e].edot_t || !ev[e].tang_t || !ev[e].coef_t) return PN_ERR_NULL;
-            ++n2;
+            if (!ev[e].edot_t || !ev[e].tang_t || (first && !ev[e].coef_t)) return PN_ERR_NULL;
+            if (second) ++n2;
         }
         if (planes == 2 && !ev[e].amax) return PN_ERR_NULL;
     }
-    if (n + n2 > 4) return PN_ERR_UNSUPPORTED;
+    if ((first ? n : 0) + n2 > 4) return PN_ERR_UNSUPPORTED;
+    if (!first && !n2) return PN_OK;  // second-order rows only, and no evaluation has any
     // planes = 2: a weight gradient sums over ALL samples, so each operand tensor gets ONE power of two, from the maxima
     // the chain kernels left in the evaluation's table
     auto run = [&](const WgJob& j) {
-        return planes == 3 ? run_wgrad_job<3>(j, work, work_floats, s)
-                           : (planes == 2 ? run_wgrad_job<2>(j, work, work_floats, s) : run_wgrad_job<1>(j, work, work_floats, s));
+        if (!j.nseg) return (int)PN_OK;
+        return planes == 3 ? run_wgrad_job<3>(j, work, work_floats, max_wgs, s)
+                           : (planes == 2 ? run_wgrad_job<2>(j, work, work_floats, max_wgs, s)
+                                          : run_wgrad_job<1>(j, work, work_floats, max_wgs, s));
     };
     auto am = [&](int e, int slot) -> const uint32_t* { return ev[e].amax ? ev[e].amax + slot : nullptr; };
     auto mp = [&](int e) { return pn_pad(ev[e].M); };
@@ -2806,29 +2830,31 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
         WgJob j{};
         for (int e = 0; e < n; ++e) {
             const int64_t Mp = mp(e);
-            j.seg[j.nseg++] = WSeg{at(ev[e].delta_t, (int64_t)l * Mp * 256), l == 0 ? ev[e].enc_t : act(e, l - 1), Mp / 16, 256,
-                                   l == 0 ? 96 : 256, 1, am(e, AM_DELTA0 + l), am(e, l == 0 ? AM_ENC : AM_ACT0 + l - 1)};
-            if (ev[e].rs_t)
+            if (first)
+                j.seg[j.nseg++] = WSeg{at(ev[e].delta_t, (int64_t)l * Mp * 256), l == 0 ? ev[e].enc_t : act(e, l - 1), Mp / 16, 256,
+                                       l == 0 ? 96 : 256, 1, am(e, AM_DELTA0 + l), am(e, l == 0 ? AM_ENC : AM_ACT0 + l - 1)};
+            if (second && ev[e].rs_t)
                 j.seg[j.nseg++] = WSeg{at(ev[e].rs_t, (int64_t)l * Mp * 256),
                                        l == 0 ? ev[e].edot_t : at(ev[e].tang_t, (int64_t)(l - 1) * Mp * 256), Mp / 16, 256,
                                        l == 0 ? 96 : 256, 0, am(e, AM_RS0 + l), am(e, l == 0 ? AM_EDOT : AM_TANG0 + l - 1)};
         }
         j.cfg = l == 0 ? 1 : 0;
         // fp16 pairs: delta_l / r_l (l = 1-4, 6, 7) and h_{l-1} / hdot_{l-1} (l >= 1) come in Q24
-        j.fmt = (planes == 2 && kQ24<2> && l >= 1) ? (q24_delta(l) ? 3 : 1) : 0;
+        j.fmt = (t_format == 1 && l >= 1) ? (q24_delta(l) ? 3 : 1) : 0;
         j.rows = 256;
         j.cols = l == 0 ? 96 : 256;
         j.dst = grads + L.w[l];
         j.ldd = l == 0 ? 96 : (l == 5 ? 352 : 256);
-        j.dbias = grads + L.b[l];
+        j.dbias = first ? grads + L.b[l] : nullptr;
         if ((rc = run(j)) != PN_OK) return rc;
         if (l == 5) {
             WgJob k{};
             for (int e = 0; e < n; ++e) {
                 const int64_t Mp = mp(e);
-                k.seg[k.nseg++] = WSeg{at(ev[e].delta_t, (int64_t)5 * Mp * 256), ev[e].enc_t, Mp / 16, 256, 96, 0,
-                                       am(e, AM_DELTA0 + 5), am(e, AM_ENC)};
-                if (ev[e].rs_t)
+                if (first)
+                    k.seg[k.nseg++] = WSeg{at(ev[e].delta_t, (int64_t)5 * Mp * 256), ev[e].enc_t, Mp / 16, 256, 96, 0,
+                                           am(e, AM_DELTA0 + 5), am(e, AM_ENC)};
+                if (second && ev[e].rs_t)
                     k.seg[k.nseg++] = WSeg{at(ev[e].rs_t, (int64_t)5 * Mp * 256), ev[e].edot_t, Mp / 16, 256, 96, 0,
                                            am(e, AM_RS0 + 5), am(e, AM_EDOT)};
             }
@@ -2837,7 +2863,7 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
             if ((rc = run(k)) != PN_OK) return rc;
         }
     }
-    {  // extra layer: d bottleneck^T h7
+    if (first) {  // extra layer: d bottleneck^T h7
         WgJob j{};
         for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].d8_t, act(e, 7), mp(e) / 16, 288, 256, 1, am(e, AM_D8B), am(e, AM_ACT0 + 7)};
         j.cfg = 0; j.rows = 256; j.cols = 256; j.dst = grads + L.we; j.ldd = 256; j.dbias = grads + L.be;
@@ -2845,12 +2871,13 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     }
     {  // density head: d raw_density^T h7 (+ softplus' rows against hdot_7 into row 0)
         WgJob j{};
-        for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{at(ev[e].d8_t, 256 * TILE), act(e, 7), mp(e) / 16, 288, 256, 1, am(e, AM_D8D), am(e, AM_ACT0 + 7)};
+        if (first)
+            for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{at(ev[e].d8_t, 256 * TILE), act(e, 7), mp(e) / 16, 288, 256, 1, am(e, AM_D8D), am(e, AM_ACT0 + 7)};
         j.cfg = 3; j.rows = nc; j.cols = 256; j.dst = grads + L.wd; j.ldd = 256; j.dbias = grads + L.bd;
         if ((rc = run(j)) != PN_OK) return rc;
-        WgJob k{};
+        WgJob k{};  // (with the first-order products: coef_t is written by the evaluation's backward chain)
         for (int e = 0; e < n; ++e)
-            if (ev[e].rs_t)
+            if (first && ev[e].rs_t)
                 k.seg[k.nseg++] = WSeg{ev[e].coef_t, at(ev[e].tang_t, (int64_t)7 * mp(e) * 256), mp(e) / 16, 32, 256, 0,
                                        am(e, AM_COEF), am(e, AM_TANG0 + 7)};
         if (k.nseg) {
@@ -2858,14 +2885,14 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
             if ((rc = run(k)) != PN_OK) return rc;
         }
     }
-    {  // view layer: d hv^T [bottleneck | view encoding]
+    if (first) {  // view layer: d hv^T [bottleneck | view encoding]
         WgJob j{};
         for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].dhv_t, act(e, 8), mp(e) / 16, 128, 288, 1, am(e, AM_DHV), am(e, AM_ACT0 + 8)};
         j.cfg = 2; j.rows = 128; j.cols = PN_WIDTH + PN_VIEW_DIM; j.dst = grads + L.wv; j.ldd = PN_WIDTH + PN_VIEW_DIM;
         j.dbias = grads + L.bv;
         if ((rc = run(j)) != PN_OK) return rc;
     }
-    {  // colour head: d rgb^T hv
+    if (first) {  // colour head: d rgb^T hv
         WgJob j{};
         for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].drgb_t, act(e, 9), mp(e) / 16, 32, 128, 1, am(e, AM_DRGB), am(e, AM_ACT0 + 9)};
         j.cfg = 4; j.rows = 3; j.cols = 128; j.dst = grads + L.wc; j.ldd = 128; j.dbias = grads + L.bc;

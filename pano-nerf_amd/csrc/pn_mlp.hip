@@ -982,7 +982,7 @@ const char* pn_strerror(int code) {
         default: return "unknown error";
     }
 }
-int pn_abi_version(void) { return 1; }
+int pn_abi_version(void) { return 2; }
 int64_t pn_pad_rows(int64_t m) { return pn_pad(m); }
 
 }  // extern "C"

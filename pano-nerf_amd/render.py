@@ -27,11 +27,12 @@ class _Eval:
     """Buffers of one MLP evaluation over M sample rows (all caller-owned HBM).  planes = 0: layer-wise GEMM path
     (row-major activations); planes = 3 / 2 / 1: fused chain kernels (T32 sample-minor tensors, see pn_chain.hip)."""
 
-    def __init__(self, M, rows_per_ray, viewdirs, nc, dev, planes=0, keep=True):
+    def __init__(self, M, rows_per_ray, viewdirs, nc, dev, planes=0, keep=True, tfmt=0):
         self.M, self.rows_per_ray, self.nc = M, rows_per_ray, nc
         self.view_rows = viewdirs.shape[0]
         self.viewdirs = viewdirs
         self.planes = planes
+        self.tfmt = tfmt  # 1: the 256-wide tensors only the weight gradients read back are Q24 (include/panonerf_hip.h)
         Mp = int(_lib.load().pn_pad_rows(M))
         self.Mp = Mp
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -56,11 +57,23 @@ class _Eval:
         self.gmean = None
 
 
+MLP_MODES = ("fused_f16x2", "fused_f16x2_t32", "fused", "fused_bf16", "layerwise")
+
+
 def _planes_of(mode):
     try:
-        return {"fused": 3, "fused_f16x2": 2, "fused_bf16": 1, "layerwise": 0}[mode]
+        return {"fused": 3, "fused_f16x2": 2, "fused_f16x2_t32": 2, "fused_bf16": 1, "layerwise": 0}[mode]
     except KeyError:
-        raise ValueError(f"mlp_mode must be 'fused', 'fused_f16x2', 'fused_bf16' or 'layerwise', got {mode!r}")
+        raise ValueError(f"mlp_mode must be one of {MLP_MODES}, got {mode!r}")
+
+
+def _tfmt_of(mode):
+    """T-tensor format of a mode (the t_format argument of the chain entry points): "fused_f16x2" stores the 256-wide
+    tensors that only the weight gradients read back in three bytes per element (Q24, 16 significant bits) where the
+    build has them; "fused_f16x2_t32" is the same arithmetic with every T tensor in fp32."""
+    if mode != "fused_f16x2":
+        return 0
+    return 1 if int(_lib.load().pn_chain_q24_slots(2, 1, 0)) else 0
 
 
 class _Cfg:
@@ -75,7 +88,7 @@ def _mlp_forward(ev, params, wpack, st):
         _lib.call("pn_chain_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, ev.planes, wpack.data_ptr(),
                   ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.viewtab.data_ptr(), ev.enc.data_ptr(),
                   _lib.ptr(ev.acts),
-                  ev.masks.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), _lib.ptr(ev.amax), st)
+                  ev.masks.data_ptr(), ev.raw_rgb.data_ptr(), ev.raw_den.data_ptr(), _lib.ptr(ev.amax), ev.tfmt, 0, st)
         return
     _lib.call("pn_mlp_forward", ev.M, ev.rows_per_ray, ev.view_rows, ev.nc, params.data_ptr(), wpack.data_ptr(),
               ev.mean.data_ptr(), ev.cov.data_ptr(), ev.viewdirs.data_ptr(), ev.enc.data_ptr(), ev.viewenc.data_ptr(),
@@ -147,44 +160,57 @@ class _ChainEvalC(ctypes.Structure):
                 ("tang_t", ctypes.c_void_p), ("coef_t", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
 
 
-def _chain_backward(ev, cfg, params, pack, d_raw_rgb, d_raw_den, v, d_mean, st):
-    """Fused data-gradient chain of one evaluation (tangent sweep first when v = dL/d(grad_mean) is given); leaves the
-    T32 tensors the weight-gradient GEMMs read on `ev`."""
+def _chain_tangent(ev, cfg, params, pack, v, st, wgs=0):
+    """Forward-mode tangent sweep along v = dL/d(grad_mean): edot, hdot_0..7 (with r_l: the second-order weight gradients)
+    and sdot (the second-order addend of the backward chain's density seed)."""
+    dev = v.device
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    Mp = ev.Mp
+    ev.edot, ev.tang, ev.sdot = e(Mp * 96), e(8 * Mp * 256), e(ev.M)
+    _lib.call("pn_chain_tangent", ev.M, ev.nc, ev.planes, params.data_ptr(), pack.data_ptr(), ev.mean.data_ptr(),
+              ev.cov.data_ptr(), ev.masks.data_ptr(), v.data_ptr(), ev.edot.data_ptr(), ev.tang.data_ptr(),
+              ev.sdot.data_ptr(), _lib.ptr(ev.amax), ev.tfmt, wgs, st)
+    z = e if _lib.load().pn_chain_tile() == 16 else (lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev))
+    ev.coef = z(Mp * 32)
+
+
+def _chain_backward(ev, cfg, params, pack, d_raw_rgb, d_raw_den, v, d_mean, st, wgs=0):
+    """Fused data-gradient chain of one evaluation (tangent sweep first when v = dL/d(grad_mean) is given, unless the caller
+    ran it: ev.sdot set); leaves the T32 tensors the weight-gradient GEMMs read on `ev`.  wgs: workgroup budget (0 = all CUs)."""
     dev = d_raw_rgb.device
     e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     # drgb / d8 / coef hold a padded k-step that the 32-sample build (pn_chain_tile() = 32) writes only half of; the
     # default 16-sample kernels write every feature of every padded row themselves (0.3 ms of fills per step)
     z = e if _lib.load().pn_chain_tile() == 16 else (lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev))
     Mp = ev.Mp
-    sdot = None
-    ev.edot = ev.tang = ev.coef = None
-    if v is not None:
-        ev.edot, ev.tang, sdot = e(Mp * 96), e(8 * Mp * 256), e(ev.M)
-        _lib.call("pn_chain_tangent", ev.M, ev.nc, ev.planes, params.data_ptr(), pack.data_ptr(), ev.mean.data_ptr(),
-                  ev.cov.data_ptr(), ev.masks.data_ptr(), v.data_ptr(), ev.edot.data_ptr(), ev.tang.data_ptr(),
-                  sdot.data_ptr(), _lib.ptr(ev.amax), st)
-        ev.coef = z(Mp * 32)
+    if v is None:
+        ev.edot = ev.tang = ev.coef = ev.sdot = None
+    elif getattr(ev, "sdot", None) is None:
+        _chain_tangent(ev, cfg, params, pack, v, st, wgs)
     ev.drgb, ev.dhv, ev.d8, ev.delta = z(Mp * 32), e(Mp * 128), z(Mp * 288), e(8 * Mp * 256)
     _lib.call("pn_chain_backward", ev.M, ev.nc, ev.planes, cfg.density_bias, pack.data_ptr(), ev.masks.data_ptr(),
-              ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(), _lib.ptr(sdot), ev.mean.data_ptr(),
+              ev.raw_den.data_ptr(), d_raw_rgb.data_ptr(), d_raw_den.data_ptr(), _lib.ptr(ev.sdot), ev.mean.data_ptr(),
               ev.cov.data_ptr(), ev.drgb.data_ptr(), ev.dhv.data_ptr(), ev.d8.data_ptr(), ev.delta.data_ptr(),
-              _lib.ptr(ev.coef), _lib.ptr(d_mean), _lib.ptr(ev.amax), st)
+              _lib.ptr(ev.coef), _lib.ptr(d_mean), _lib.ptr(ev.amax), ev.tfmt, wgs, st)
 
 
-def _chain_wgrad(evals, nc, planes, flat_grad, st):
-    """One TN GEMM per layer over the sample blocks of every evaluation of the step."""
+def _chain_wgrad(evals, nc, planes, flat_grad, st, which=3, wgs=0):
+    """One TN GEMM per layer over the sample blocks of the given evaluations (all of the step's, or - concurrent schedule -
+    one at a time).  which: 1 first-order products, 2 second-order trunk rows, 3 both (include/panonerf_hip.h)."""
     lib = _lib.load()
     arr = (_ChainEvalC * len(evals))()
     for i, ev in enumerate(evals):
         second = ev.tang is not None
-        arr[i] = _ChainEvalC(ev.M, ev.enc.data_ptr(), ev.acts.data_ptr(), ev.drgb.data_ptr(), ev.dhv.data_ptr(),
-                             ev.d8.data_ptr(), ev.delta.data_ptr(), ev.rsweep.data_ptr() if second else None,
+        first = bool(which & 1)  # (the second-order trunk rows alone are reduced before the evaluation's backward chain has run)
+        arr[i] = _ChainEvalC(ev.M, ev.enc.data_ptr(), ev.acts.data_ptr(), ev.drgb.data_ptr() if first else None,
+                             ev.dhv.data_ptr() if first else None, ev.d8.data_ptr() if first else None,
+                             ev.delta.data_ptr() if first else None, ev.rsweep.data_ptr() if second else None,
                              ev.edot.data_ptr() if second else None, ev.tang.data_ptr() if second else None,
                              ev.coef.data_ptr() if second else None, _lib.ptr(ev.amax))
     n = int(lib.pn_chain_wgrad_work_floats())
     work = torch.empty(n, dtype=torch.float32, device=flat_grad.device)
     _lib.check(lib.pn_chain_wgrad(len(evals), ctypes.cast(arr, ctypes.c_void_p), nc, planes, flat_grad.data_ptr(),
-                                  work.data_ptr(), n, st), "pn_chain_wgrad")
+                                  work.data_ptr(), n, which, evals[0].tfmt, wgs, st), "pn_chain_wgrad")
     return work
 
 
@@ -209,7 +235,7 @@ class _RenderFn(torch.autograd.Function):
             e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             keep = cfg.keep  # inference (no_grad): release the big activation buffers as soon as possible
             # ---- level 0: stratified samples
-            e0 = _Eval(M, N, vd, nc, dev, planes, keep)
+            e0 = _Eval(M, N, vd, nc, dev, planes, keep, cfg.tfmt)
             e0.t = e(B, S)
             _lib.call("pn_sample_coarse", B, N, int(cfg.disparity), o.data_ptr(), d.data_ptr(), radii.data_ptr(), near.data_ptr(),
                       far.data_ptr(), _lib.ptr(t_rand), e0.t.data_ptr(), e0.mean.data_ptr(), e0.cov.data_ptr(), st)
@@ -218,7 +244,7 @@ class _RenderFn(torch.autograd.Function):
             if not keep:
                 e0.acts = e0.masks = e0.enc = None
             # ---- level 1: PDF resample (no gradient through the weights: stop_resample_grad)
-            e1 = _Eval(M, N, vd, nc, dev, planes, keep)
+            e1 = _Eval(M, N, vd, nc, dev, planes, keep, cfg.tfmt)
             e1.t = e(B, S)
             _lib.call("pn_resample", B, N, e0.t.data_ptr(), w0.data_ptr(), cfg.resample_padding, _lib.ptr(u_rand),
                       o.data_ptr(), d.data_ptr(), radii.data_ptr(), e1.t.data_ptr(), e1.mean.data_ptr(),
@@ -235,7 +261,7 @@ class _RenderFn(torch.autograd.Function):
                     _lib.call("pn_chain_density_grad", M, nc, planes, cfg.density_bias, params.data_ptr(),
                               wpack.data_ptr(), e1.mean.data_ptr(), e1.cov.data_ptr(), e1.masks.data_ptr(),
                               e1.raw_den.data_ptr(), e1.rsweep.data_ptr(), int(keep), e1.gmean.data_ptr(),
-                              _lib.ptr(e1.amax), st)
+                              _lib.ptr(e1.amax), e1.tfmt, 0, st)
                 else:
                     scratch = e(e1.Mp, 96)
                     _lib.call("pn_density_grad", M, nc, cfg.density_bias, params.data_ptr(), wpack.data_ptr(),
@@ -255,7 +281,7 @@ class _RenderFn(torch.autograd.Function):
                 e1.acts = e1.masks = e1.enc = None
             if cfg.surf:
                 D, Ne = env_d.shape[0], cfg.num_env_samples
-                ee = _Eval(B * D * Ne, Ne, env_d, nc, dev, planes, keep)
+                ee = _Eval(B * D * Ne, Ne, env_d, nc, dev, planes, keep, cfg.tfmt)
                 ee.t = e(B * D, Ne + 1)
                 _lib.call("pn_sample_env", B, D, Ne, o.data_ptr(), d.data_ptr(), dist1.data_ptr(), env_d.data_ptr(),
                           env_rad.data_ptr(), env_near.data_ptr(), env_far.data_ptr(), _lib.ptr(env_rand),
@@ -319,9 +345,42 @@ class _RenderFn(torch.autograd.Function):
 
         gz = lambda g, *s: _f32(g) if g is not None else z(*s)
         with torch.cuda.device(dev):
-            st = torch.cuda.current_stream(dev).cuda_stream
+            main = torch.cuda.current_stream(dev)
+            st = main.cuda_stream
             flat_grad = torch.zeros(params.numel(), dtype=torch.float32, device=dev)  # outlives this call (.grad views)
+            # CONCURRENT WEIGHT GRADIENTS (fused chains, cfg.overlap): the weight-gradient GEMMs of an evaluation start on a side
+            # stream as soon as its backward chain is done and run beside the next evaluation's chains, each kernel family on its
+            # share of the CUs (cfg.chain_wgs / cfg.wgrad_wgs: a chain workgroup and a 256-wide weight-gradient workgroup fill a
+            # CU each, so the two launches occupy disjoint CUs) - the chains are bound by matrix-instruction issue and their T
+            # stores, the weight gradients by their operand reads.  Level 0, whose gradient depends on nothing of level 1, goes
+            # first so that its weight gradients have the env-light and level-1 chains to run under; the second-order trunk rows
+            # of level 1 (r_l^T hdot_{l-1}: complete after the tangent sweep) run under its backward chain; only its first-order
+            # products are left for the end, on the whole chip.  All reductions into flat_grad happen on the side stream, in a
+            # fixed order.
+            conc = bool(cfg.planes) and bool(cfg.overlap)
+            side = _side_stream(dev) if conc else None
+            cw, ww = (cfg.chain_wgs, cfg.wgrad_wgs) if conc else (0, 0)
+            held = []  # workspaces of the side-stream jobs (kept until the join)
+
+            def wg(evals, which=3, wgs=0):
+                if not conc:
+                    _chain_wgrad(evals, nc, cfg.planes, flat_grad, st, which, wgs)
+                    return
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    held.append(_chain_wgrad(evals, nc, cfg.planes, flat_grad, side.cuda_stream, which, wgs))
+
+            def level0():
+                d_rr0, d_rd0 = z(M, 3), z(M, nc)
+                _composite_backward(e0, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp0, B, 3), gz(g_dist0, B), None, d_rr0,
+                                    d_rd0, st)
+                return d_rr0, d_rd0
+
             pending = []  # (evaluation, its workspace, ran the tangent sweep): weight gradients batched into the last call
+            if conc:
+                d_rr0, d_rd0 = level0()
+                _chain_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, st)  # (alone on the chip: every CU)
+                wg([e0], 3, ww)
             d_dist1 = gz(g_dist1, B).clone() if g_dist1 is not None else z(B)  # (accumulated into below: a private buffer)
             d_normal = gz(g_normal, B, 3) if cfg.normals else None
             d_albedo = None
@@ -342,8 +401,11 @@ class _RenderFn(torch.autograd.Function):
                 _composite_backward(ee, B * D, Ne, cfg, False, env_d, D, d_env, None, None, d_rr, d_rd, st)
                 d_mean_e = z(ee.M, 3)
                 if cfg.planes:
-                    _chain_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, st)
-                    pending.append(ee)
+                    _chain_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, st, cw)
+                    if conc:
+                        wg([ee], 3, ww)
+                    else:
+                        pending.append(ee)
                 else:
                     pending.append((ee, _mlp_backward(ee, cfg, params, wpack, d_rr, d_rd, None, d_mean_e, flat_grad, st,
                                                       defer=cfg.batch_wgrad), False))
@@ -360,23 +422,32 @@ class _RenderFn(torch.autograd.Function):
                           _lib.ptr(d_albedo), d_w1.data_ptr(), v.data_ptr(), d_rd.data_ptr(), st)
             _composite_backward(e1, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp1, B, 3), d_dist1, d_w1, d_rr, d_rd, st)
             if cfg.planes:
-                _chain_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, st)
-                pending.append(e1)
+                e1.sdot = None
+                if conc and v is not None:
+                    _chain_tangent(e1, cfg, params, wpack, v, st, cw)
+                    wg([e1], 2, ww)  # second-order trunk rows, under the backward chain
+                _chain_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, st, cw)
+                if conc:
+                    wg([e1], 1 if v is not None else 3, 0)  # what is left runs alone: every CU
+                else:
+                    pending.append(e1)
             else:
                 pending.append((e1, _mlp_backward(e1, cfg, params, wpack, d_rr, d_rd, v, None, flat_grad, st,
                                                   defer=cfg.batch_wgrad), v is not None))
                 if not cfg.batch_wgrad:
                     pending = []
-            d_rr0, d_rd0 = z(M, 3), z(M, nc)
-            _composite_backward(e0, B, N, cfg, cfg.white_bkgd, d, B, gz(g_comp0, B, 3), gz(g_dist0, B), None, d_rr0,
-                                d_rd0, st)
-            if cfg.planes:
-                _chain_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, st)
-                pending.append(e0)
-                _chain_wgrad(pending, nc, cfg.planes, flat_grad, st)
+            if conc:
+                main.wait_stream(side)
             else:
-                _mlp_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, flat_grad, st, deferred=pending)
+                d_rr0, d_rd0 = level0()
+                if cfg.planes:
+                    _chain_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, st)
+                    pending.append(e0)
+                    _chain_wgrad(pending, nc, cfg.planes, flat_grad, st)
+                else:
+                    _mlp_backward(e0, cfg, params, wpack, d_rr0, d_rd0, None, None, flat_grad, st, deferred=pending)
             pending = []
+            held = []
         mlp.last_flat_grad = flat_grad
         ctx.pack = None
         if getattr(mlp, "defer_param_grads", False):
@@ -436,6 +507,10 @@ class _RenderBase(torch.nn.Module):
         # weight gradients of the three evaluations batched (below) the chip is power-limited either way and the
         # time-shared run measured 2 % SLOWER (62.4 k vs 61.0 k rays/s at 4096 rays, 50.8 k vs 49.4 k at 512)
         self.overlap_weight_grads = False
+        # fused chains with overlap_weight_grads: workgroups (= CUs) the chains / the weight-gradient jobs may occupy while they
+        # run side by side (0 = no limit: the two families then take turns on whole-chip launches)
+        self.overlap_chain_wgs = 112
+        self.overlap_wgrad_wgs = 144
         self.batch_weight_grads = True    # one weight-gradient GEMM per layer over env + level-1 + level-0 rows
         # MLP arithmetic / kernel family.  "fused_f16x2" (default) = on-chip chains, every fp32 operand as an fp16 pair
         # x 2^e = h + l (|error| < 2^-24 |x|; one power-of-two scale per weight matrix and per sample / tensor), three
@@ -480,6 +555,7 @@ class _RenderBase(torch.nn.Module):
                    rgb_padding=self.rgb_padding, resample_padding=self.resample_padding, disparity=self.disparity,
                    white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
                    num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads, planes=_planes_of(self.mlp_mode),
+                   tfmt=_tfmt_of(self.mlp_mode), chain_wgs=int(self.overlap_chain_wgs), wgrad_wgs=int(self.overlap_wgrad_wgs),
                    batch_wgrad=self.batch_weight_grads,
                    keep=torch.is_grad_enabled() and any(p.requires_grad for p in self.mlp.parameters()))
         plist = [p for _, p in self.mlp.named_in_order()]

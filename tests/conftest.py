@@ -64,7 +64,18 @@ def assert_close(got, ref, name, tol=1e-4, elementwise_tol=1e-4):
     return e, ee
 
 
+WORST_LOG = {}  # label -> worst value over the session (gradient errors per kernel mode etc.): printed at the end
+
+
+def report_worst(label, value):
+    WORST_LOG[label] = max(WORST_LOG.get(label, 0.0), float(value))
+
+
 def pytest_terminal_summary(terminalreporter):
+    if WORST_LOG:
+        terminalreporter.write_line("worst errors over this session:")
+        for k in sorted(WORST_LOG):
+            terminalreporter.write_line(f"  {k}: {WORST_LOG[k]:.2e}")
     if ELEMENTWISE_LOG:
         worst = {}
         for name, e, ee in ELEMENTWISE_LOG:

@@ -56,7 +56,7 @@ def test_library_exports_every_symbol():
     handle = lib.load()
     for name in parse_header():
         assert hasattr(handle, name), name
-    assert handle.pn_abi_version() == 1
+    assert handle.pn_abi_version() == 2
     assert handle.pn_pad_rows(1) == 128 and handle.pn_pad_rows(128) == 128 and handle.pn_pad_rows(129) == 256
     off = (ctypes.c_int64 * 24)()
     assert handle.pn_param_layout(5, off) == 613768

@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("graph", ["off", "on"])
+@pytest.mark.parametrize("graph", ["off", "on", "on-capture-fails-on-rank-1"])
 def test_two_rank_bench_flow(graph):
     env = dict(os.environ, PN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    fail = graph.startswith("on-")
+    if fail:  # a capture that throws on ONE rank must send BOTH ranks to eager launches through the same collective
+        env["PN_BENCH_FAIL_CAPTURE_RANK"] = "1"
+        graph = "on"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--global-batch", "256", "--samples", "32", "--height", "64", "--width", "128", "--graph",
@@ -36,7 +40,10 @@ def test_two_rank_bench_flow(graph):
     assert audit["rays_per_rank"] == [128, 128] and len(audit["last_loss_per_rank"]) == 2
     assert audit["last_loss_per_rank"][0] != audit["last_loss_per_rank"][1]
     assert audit["allreduced_grad_l2"] > 0 and audit["allreduced_grad_l2_spread_over_ranks"] == 0.0
-    if graph == "on":  # the captured step was checked against an eager step on the same batch before it was timed
+    if fail:
+        assert out["config"]["launch"].startswith("eager (graph capture failed")
+        assert out["config"]["replay_check"]["ok_all_ranks"] is False and out["config"]["replay_check"]["ok_this_rank"] is True
+    elif graph == "on":  # the captured step was checked against an eager step on the same batch before it was timed
         assert out["config"]["launch"] == "hip-graph replay"
         assert out["config"]["replay_check"]["ok_all_ranks"] is True
         assert out["config"]["replay_check"]["max_grad_diff_over_max_grad"] <= 1e-6

@@ -90,7 +90,7 @@ def check_grads(model, g, prefix):
         assert float(np.median(err)) < 1e-4 * max(float(np.max(np.abs(ref))), 1e-12), (k, float(np.median(err)))
 
 
-MODES = ["fused", "fused_f16x2", "layerwise"]  # on-chip chains with the exact 3-term bf16 split (default) / one fp32-MFMA GEMM per layer
+MODES = ["fused", "fused_f16x2", "fused_f16x2_t32", "layerwise"]  # on-chip chains with the exact 3-term bf16 split (default) / one fp32-MFMA GEMM per layer
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -255,11 +255,11 @@ def test_bench_size_properties():
 def test_headline_size_matches_oracle_on_a_ray_subset(mode):
     """The BASELINE / bench.py size - 4096 rays x 128 + 128 samples (M = 524 288 rows per level, 16 tiles per persistent
     workgroup, 409 600 env-light rows), train mode with fixed noise - checked against the oracle: rays are independent, so
-    the oracle run on a strided 32-ray subset (with those rays' noise rows) must reproduce the subset of every per-ray
+    the oracle run on a strided 128-ray subset (with those rays' noise rows) must reproduce the subset of every per-ray
     output of the 4096-ray call.  Plus the size-independent properties of test_bench_size_properties.
     Reference: models/pano_mip_nerf.py:197-363."""
     import pano_nerf_amd as pn
-    B, N, K = 4096, 128, 32
+    B, N, K = 4096, 128, 128
     S = N + 1
     flat, rgbs, radius, _ = orc.synthetic_scene(64, 128, 3, seed=4)
     idx = torch.randint(0, flat.origins.shape[0], (B,), generator=torch.Generator().manual_seed(4096))
@@ -280,13 +280,16 @@ def test_headline_size_matches_oracle_on_a_ray_subset(mode):
     loss.backward()
     grad = model.mlp.last_flat_grad
     assert bool(torch.isfinite(loss)) and bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0
-    # ---- the oracle on every 128th ray
+    # ---- the oracle on every 32nd ray
     sub = torch.arange(0, B, B // K)
     sub_rays = orc.Rays(*[x[sub] for x in rays_c])
     sub_noise = dict(t_rand=noise["t_rand"][sub], u_rand=noise["u_rand"][sub], env_rand=noise["env_rand"])
     p = orc.init_params(4, 5)
     with torch.no_grad():
         ref = orc.pano_forward(p, sub_rays, env_c, num_samples=N, noise=sub_noise)
+        ref64 = orc.pano_forward({k: v.double() for k, v in p.items()}, orc.Rays(*[x.double() for x in sub_rays]),
+                                 orc.Rays(*[x.double() for x in env_c]), num_samples=N,
+                                 noise={k: v.double() for k, v in sub_noise.items()})
     # (a) the oracle as it stands: well-conditioned outputs at 1e-4 (tensor scale AND element-wise); the outputs derived from
     # the density gradient (a ReLU gate with a pre-activation of ~1e-7 flips under any fp32 summation order and moves one
     # ray: with 128 samples a ray a few of the 32 rays sit on such a gate) on the median only
@@ -301,6 +304,13 @@ def test_headline_size_matches_oracle_on_a_ray_subset(mode):
                 scale = max(float(np.abs(want).max()), 1e-12)
                 per_ray = np.abs(got - want).reshape(K, -1).max(-1) / scale
                 assert float(np.median(per_ray)) < 1e-4, (key, float(np.median(per_ray)))
+                # SURVEY.md 7's ">= 99 % of the elements within 1e-3": at 128 samples a ray fp32 itself does not deliver it (the
+                # fp32 oracle has 93 - 96 % of these elements within 1e-3 of its own fp64 run), so the fraction is stated against
+                # the fp64 oracle next to the fp32 oracle's own (tests/test_gpu_scale.py does the same over 1024 rays)
+                want64 = ref64[lvl][NAMES9.index(nme)].numpy()
+                ours = float(np.mean(np.abs(got - want64) <= 1e-3 * scale))
+                theirs = float(np.mean(np.abs(want - want64) <= 1e-3 * scale))
+                assert ours >= min(0.99, theirs - 0.03), (key, "fraction of elements within 1e-3 of the fp64 run: ours, the fp32 oracle's", ours, theirs)
             else:
                 assert_close(got, want, key)
     # (b) the oracle on the gate decisions the kernels took for these rays: EVERY per-ray output pointwise at 1e-4

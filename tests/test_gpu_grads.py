@@ -23,7 +23,7 @@ from test_gpu_full import dev, env_of, make_pano, rays_of, to_dev
 
 pytestmark = pytest.mark.gpu
 CASES = ["B64_N32", "B16_N128"]
-MODES = ["fused", "fused_f16x2", "layerwise"]
+MODES = ["fused", "fused_f16x2", "fused_f16x2_t32", "layerwise"]
 FIRST_ORDER = ("extra_layer", "view_layers", "color_layer")
 
 
@@ -238,3 +238,5 @@ def test_gate_consistent_gradients_pointwise(golden, case, mode):
         worst = max(worst, e)
         assert e <= 1e-4, (k, e)
     print(f"gate-consistent gradients {case} {mode}: worst tensor max-error {worst:.2e}")
+    from conftest import report_worst
+    report_worst(f"gate-consistent gradients vs the oracle, worst tensor max-error / tensor max [{mode}]", worst)

@@ -66,7 +66,7 @@ def schedule_pano(steps, B, N, H, W, seed=11):
         yield idx, t_rand, u_rand, env_rand
 
 
-@pytest.mark.parametrize("mode", ["fused", "fused_f16x2", "layerwise"])
+@pytest.mark.parametrize("mode", ["fused", "fused_f16x2", "fused_f16x2_t32", "layerwise"])
 def test_pano_training_matches_reference_trace(golden, mode):
     """The north-star PSNR target is for the panonerf step: surface + chromaticity + orientation terms, second-order
     gradients (systems/panonerf_system.py:15-75).  Same weights, batches and all three noise draws as the imported
