@@ -350,9 +350,10 @@ struct Ring {
         pslot = (pslot + 1 == Cfg<NP>::NSLOT) ? 0 : pslot + 1;
     }
     // An LDS-DMA instruction costs the issuing wave 60-185 cycles whatever it carries (MI355X_MICROARCH.md, cycle
-    // constants) and a wave's GEMM phase is paced by that, so the aux KB travels only with the rounds that can refill the
-    // FIRST chunk of a GEMM with a bias (AUX; decided statically by the GEMM step: a run-time test cost far more than the
-    // instruction - its branch splits the step sequence into blocks with full waits at their joins).
+    // constants).  The aux KB (the bias of a GEMM, in its LAST chunk's slot) travels with EVERY round (AUX is always true):
+    // leaving it out of the rounds that cannot reach a chunk with a bias saved 14 % of the DMA instructions and no time, and as
+    // a run-time test it cost far more than the instruction (a branch splits the step sequence into blocks with full waits at
+    // their joins).  Waves 0-3 therefore issue CF / CH_WAVES + 1 instructions per round, waves 4-7 CF / CH_WAVES.
     template <int I, bool AUX>
     __device__ __forceinline__ void piece() {
         if constexpr (I < CF / CH_WAVES) {
@@ -387,6 +388,9 @@ struct Ring {
     unsigned long long t_lds = 0, t_dma = 0, t_bar = 0, n_acq = 0;
 #endif
     __device__ __forceinline__ uint32_t acquire() {
+        // my share of the oldest chunk in flight has landed when at most the D - 1 younger rounds are outstanding.  Counted with
+        // SHARE = CF / CH_WAVES per round although waves 0-3 issue one more (the aux quarter): for them the wait is one round's
+        // aux piece stricter than necessary (it over-waits, never under-waits: vmcnt retires in issue order)
         constexpr int N = Cfg<NP>::SHARE * (Cfg<NP>::D - 1);
 #ifdef PN_TRACE_CHAIN
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -891,6 +895,12 @@ constexpr bool kQ24 = (NP == 2 && TILE == 16 && !PN_NO_Q24);
 __host__ __device__ constexpr bool q24_act(int slot) { return slot <= 6; }                  // h_l / hdot_l
 __host__ __device__ constexpr bool q24_delta(int slot) { return slot != 0 && slot != 5; }   // delta_l / r_l
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+// Non-finite values: Inf stays Inf (0x7F800000 + 0x80 keeps its three upper bytes) and the NaN the hardware generates (0x7FC00000, and
+// every quiet NaN whose payload does not reach bits 8 - 22 all set) stays a NaN, so a diverged activation or delta still gives a
+// non-finite weight gradient (tests/test_gpu_chain.py::test_non_finite_values_survive_q24); the largest finite values (|x| >=
+// 0x7F7FFF80) round up to Inf, as round-to-nearest does; only a NaN with payload bits 7 - 22 all ones (0x7FFFFF80 ...: never
+// produced by arithmetic here) would wrap to zero - an exponent test per element (two more vector instructions on 26 K elements a
+// sample) is not spent on it.  pano_nerf_amd.tlayout.q24_encode mirrors this bit for bit.
 __device__ __forceinline__ u32x3 pack_q24(float x0, float x1, float x2, float x3) {
     // round to nearest on the dropped byte (ties away from zero: one tie in 256, a bias of 2^-26), then bytes 1-3 of each element
     const uint32_t e0 = __float_as_uint(x0) + 0x80u, e1 = __float_as_uint(x1) + 0x80u;
@@ -2176,7 +2186,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     };
     if constexpr (ALT) {
         // ALTERNATING ORDER.  In the common order (below) both waves of a SIMD stage, then both multiply; the phase trace
-        // (tools/trace_wgrad.py) showed the second-dispatched wave of every SIMD losing the arbitration for the matrix pipe,
+        // (tools/experiments/trace_wgrad.py) showed the second-dispatched wave of every SIMD losing the arbitration for the matrix pipe,
         // finishing its products last and only then starting to stage: the pipe idle for half of every half block.  Here wave
         // type t (0: waves 0 .. NW/2 - 1, 1: their SIMD partners) runs   products(K) ; stage(K + 1 + t) ; refill   per half block
         // K - ONE instruction sequence - with its barrier behind the products (t = 1) or behind the staging (t = 0): after a
@@ -2440,8 +2450,12 @@ static int pack_both(int nc, const float* params, unsigned char* out, hipStream_
     return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, wexp + F_COUNT, s);
 }
 
-// Per-device launch state: the chains need 75 KB of dynamic LDS, an attribute that is set per (kernel, device), and the grid
-// is sized by the device's CU count - a process may drive several devices (one host thread per device).
+// Per-device launch state: the chains need Cfg<NP>::LDS_BYTES of dynamic LDS (the ring: 5 slots x 25 KB = 125 KB with fp16 pairs
+// or the bf16 split in the default 8-wave form, 4 x 33 KB with plain bf16), an attribute that is set per (kernel, device), and the
+// grid is sized by the device's CU count - a process may drive several devices (one host thread per device).
+static_assert(Cfg<1>::LDS_BYTES <= 160 * 1024 && Cfg<2>::LDS_BYTES <= 160 * 1024 && Cfg<3>::LDS_BYTES <= 160 * 1024,
+              "the weight ring must fit a CU's 160 KB of LDS");
+static_assert(PN_ROW_PAD % CH_SAMPLES == 0, "sample buffers are padded to whole workgroup tiles");
 constexpr int PN_MAX_DEVICES = 64;
 static int current_device() {
     int dev = 0;

@@ -957,7 +957,7 @@ int pn_gemm_nt(int64_t M, int N, int K, const float* A, int lda, const float* Bt
     g.gate = gate;
     g.ldg = ldg;
     #ifdef PN_ABLATE
-    g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE | 0x300);  // 0x100/0x200: ablation (tools/bench_gemm.py)
+    g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE | 0x300);  // 0x100/0x200: ablation (tools/experiments/bench_gemm.py)
 #else
     g.flags = flags & (PN_EPI_BIAS | PN_EPI_RELU | PN_EPI_GATE);
 #endif

@@ -4,7 +4,7 @@ Rays are independent until the gradient sum, so a batch can be cut into sub-batc
 run side by side.  Every GEMM of one chain is followed by a GEMM that depends on it, so a chain alone leaves the
 matrix cores idle while a kernel's first tiles load and its last tiles store (4.9 us + ~18 us of a 72 us workgroup
 life at 4096 rays; a whole wave of tiles at 512 rays); a second, independent chain fills those gaps.  Measured on one
-MI355X (`tools/bench_concurrent.py`, graph replay): 512 rays 9.53 -> 9.06 ms, 1024 rays 16.86 -> 16.23 ms, 4096 rays 60.9 -> 59.6 ms per step;
+MI355X (`tools/experiments/bench_concurrent.py`, graph replay): 512 rays 9.53 -> 9.06 ms, 1024 rays 16.86 -> 16.23 ms, 4096 rays 60.9 -> 59.6 ms per step;
 four parts are no better than two.
 
 The result is the gradient of the mean loss over the whole batch: sub-batch losses are means over their rays, so the

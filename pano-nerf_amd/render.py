@@ -507,6 +507,14 @@ class _RenderBase(torch.nn.Module):
         # weight gradients of the three evaluations batched (below) the chip is power-limited either way and the
         # time-shared run measured 2 % SLOWER (62.4 k vs 61.0 k rays/s at 4096 rays, 50.8 k vs 49.4 k at 512)
         self.overlap_weight_grads = False
+        self.cache_env_rays = True          # see invalidate_env_cache
+        # see _replayed.  Off by default: measured on the bench's 512 x 1024 panorama in 512-ray chunks (the reference's
+        # validation loop) the eager launches are already GPU-bound - 0.884 s per panorama against 0.733 s in 32 768-ray chunks -
+        # and the replayed loop, which adds six input copies and ten output clones per chunk, took 0.926 s
+        self.replay_inference = False
+        self.replay_inference_max_rays = 4096
+        self._replays = {}
+        self._env_key = self._env_f32 = self._env_src = None
         # fused chains with overlap_weight_grads: workgroups (= CUs) the chains / the weight-gradient jobs may occupy while they
         # run side by side (0 = no limit: the two families then take turns on whole-chip launches)
         self.overlap_chain_wgs = 112
@@ -534,22 +542,37 @@ class _RenderBase(torch.nn.Module):
         env_rand = torch.rand(1, self.num_env_samples + 1, device=dev) if want_env else None
         return t_rand, u_rand, env_rand
 
+    def invalidate_env_cache(self):
+        """Forget the cached fp32 copies of the caller's env rays (and the captured inference graphs that read them).  The
+        cache is keyed on the source tensors' address, version counter, dtype and shape: call this after a write that bypasses
+        the version counters (`.data.copy_`, a numpy alias of a CPU tensor, a raw device write) - or set `cache_env_rays =
+        False` to convert on every call."""
+        self._env_key = self._env_f32 = self._env_src = None
+        self._replays = {}
+
+    def _env_inputs(self, env_rays, surf, dev):
+        if env_rays is None or not surf:
+            return [torch.zeros(1, 3, device=dev)] + [torch.zeros(1, device=dev)] * 4, None
+        # the caller's env rays are the same fp16 tensors every step (systems/base_system.py:57-79): their fp32 device
+        # copies are cached on the tensors' identity and version (five conversion launches per step otherwise)
+        src = (env_rays.directions, env_rays.radii, env_rays.near, env_rays.far, env_rays.lossmult)
+        conv = lambda: [_f32(src[0].to(dev))] + [_f32(x.to(dev)).reshape(-1) for x in src[1:]]
+        # no cache while a HIP graph is being captured by the CALLER: tensors made during a capture live in the graph's private
+        # pool and hold garbage until the first replay - later eager forwards must not find them here
+        if not self.cache_env_rays or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            return conv(), None
+        key = tuple((x.data_ptr(), x._version, x.dtype, tuple(x.shape)) for x in src) + (str(dev),)
+        if getattr(self, "_env_key", None) != key:
+            self._env_f32 = conv()
+            self._env_key = key
+            self._env_src = src  # keeps the sources alive: their addresses cannot be handed to other tensors meanwhile
+        return self._env_f32, key
+
     def _run(self, rays, env_rays, randomized, white_bkgd, surf, use_ort, normals):
         o, d, vd = _f32(rays.origins), _f32(rays.directions), _f32(rays.viewdirs)
         radii, near, far = _f32(rays.radii).reshape(-1), _f32(rays.near).reshape(-1), _f32(rays.far).reshape(-1)
         dev = o.device
-        if env_rays is not None and surf:
-            # the caller's env rays are the same fp16 tensors every step (systems/base_system.py:57-79): their fp32 device
-            # copies are cached on the tensors' identity and version (five conversion launches per step otherwise)
-            src = (env_rays.directions, env_rays.radii, env_rays.near, env_rays.far, env_rays.lossmult)
-            key = tuple((x.data_ptr(), x._version, x.dtype, tuple(x.shape)) for x in src) + (str(dev),)
-            if getattr(self, "_env_key", None) != key:
-                self._env_f32 = [_f32(src[0].to(dev))] + [_f32(x.to(dev)).reshape(-1) for x in src[1:]]
-                self._env_key = key
-                self._env_src = src  # keeps the sources alive: their addresses cannot be handed to other tensors meanwhile
-            env = self._env_f32
-        else:
-            env = [torch.zeros(1, 3, device=dev)] + [torch.zeros(1, device=dev)] * 4
+        env, env_key = self._env_inputs(env_rays, surf, dev)
         t_rand, u_rand, env_rand = self._noise(randomized, o.shape[0], dev, surf)
         cfg = _Cfg(num_samples=self.num_samples, nc=self._NC, density_bias=self.density_bias,
                    rgb_padding=self.rgb_padding, resample_padding=self.resample_padding, disparity=self.disparity,
@@ -559,9 +582,54 @@ class _RenderBase(torch.nn.Module):
                    batch_wgrad=self.batch_weight_grads,
                    keep=torch.is_grad_enabled() and any(p.requires_grad for p in self.mlp.parameters()))
         plist = [p for _, p in self.mlp.named_in_order()]
+        if (self.replay_inference and not cfg.keep and not randomized and dev.type == "cuda"
+                and 0 < o.shape[0] <= self.replay_inference_max_rays and (env_key is not None or not cfg.surf)
+                and not getattr(self.mlp, "debug_keep", False) and not torch.cuda.is_current_stream_capturing()):
+            return self._replayed(cfg, (o, d, vd, radii, near, far), env, env_key, plist), cfg
         outs = _RenderFn.apply(cfg, self.mlp, o, d, vd, radii, near, far, *env, t_rand, u_rand,
                                None if env_rand is None else env_rand.reshape(-1), *plist)
         return outs, cfg
+
+    def _replayed(self, cfg, inputs, env, env_key, plist):
+        """A no-grad, non-randomized forward of a small ray chunk - the reference's validation loop calls the model 1 024 times
+        per 512 x 1024 panorama with 512-ray chunks (systems/panonerf_system.py:133-192, configs/panonerf.yaml:22) - is ~70
+        launches of a few microseconds each: launch-bound.  The launch sequence of such a call is captured ONCE per (chunk
+        size, flags, kernel mode, stream) into a HIP graph over static input buffers and replayed for every later chunk: copy
+        the chunk's rays in, one graph launch, clone the outputs out.  The captured sequence re-packs the weights from the live
+        parameter block like every forward, so an optimizer step between two calls is seen; results are bit-identical to the
+        eager call's (same kernels, same order)."""
+        dev = inputs[0].device
+        stream = torch.cuda.current_stream(dev)
+        # everything the captured launch sequence depends on: the chunk size, every scalar of the call's configuration, the env
+        # rays' identity, the parameter block's address, the stream (two streams must not share static buffers) and whether
+        # the caller froze the weight packs (renderer.render_image with several streams: the capture then holds no re-pack)
+        key = (inputs[0].shape[0], tuple(sorted(cfg.__dict__.items())), env_key, self.mlp.flat_params().data_ptr(),
+               stream.cuda_stream, str(dev), bool(self.mlp._frozen))
+        ent = self._replays.get(key)
+        if ent is None:
+            if len(self._replays) >= 8:  # a few chunk sizes at most (the full chunks and the ragged last one)
+                self._replays.pop(next(iter(self._replays)))
+            static = [torch.empty_like(x) for x in inputs]
+            for sx, x in zip(static, inputs):
+                sx.copy_(x)
+            run = lambda: _RenderFn.apply(cfg, self.mlp, *static, *env, None, None, None, *plist)
+            with torch.no_grad():
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(stream)
+                with torch.cuda.stream(side):
+                    run()  # warm-up outside the capture (allocator, lazily set kernel attributes)
+                stream.wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    outs = run()
+            ent = (graph, static, outs)
+            self._replays[key] = ent
+        graph, static, outs = ent
+        for sx, x in zip(static, inputs):
+            sx.copy_(x)
+        graph.replay()
+        # (ort_loss and the absent outputs are zero-dim placeholders: cloned like the rest - the caller may keep them)
+        return tuple(x.clone() for x in outs)
 
 
 class PanoMipNeRF(_RenderBase):

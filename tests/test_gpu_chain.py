@@ -410,3 +410,35 @@ def test_large_weight_gradient_sums_against_fp64_and_an_fp32_gemm(M, ray_spread,
             assert row["ours"][0] < 2e-6 or row["ours"][0] <= row["fp32 gemm"][0], (k, row)
             assert row["ours"][1] <= max(1e-4, row["fp32 gemm"][1]), (k, row)
 
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_values_survive_q24(bad):
+    """pack_q24 rounds with `bits + 0x80`.  Inf and the NaN arithmetic produces keep their upper bytes, so a diverged
+    activation (h_2) or delta (delta_3) still gives a non-finite weight gradient in the default mode (t_format 1) - a divergence
+    must not vanish in the weight gradients."""
+    from pano_nerf_amd import _lib
+    from pano_nerf_amd.mlp import param_layout
+    lib = _lib.load()
+    if not int(lib.pn_chain_q24_slots(2, 1, 0)):
+        pytest.skip("this build has no Q24 tensors")
+    nc, M = 5, 2048
+    offs, total = param_layout(nc)
+    for where in ("act", "delta"):
+        gen = torch.Generator(device=dev()).manual_seed(3)
+        ev, bufs, want, _ = _synthetic_eval(lib, M, nc, gen, 0.0, 1)
+        # overwrite ONE element of h_2 / delta_3 (both Q24 slots, operands of layers.3.0.weight) through the host-side encoder
+        slot, buf = (2, bufs["acts_t"]) if where == "act" else (3, bufs["delta_t"])
+        rows = tl.slot_rows(lib, buf[slot * M * 256:(slot + 1) * M * 256], M, 256, True).clone()
+        rows[777, 33] = bad
+        tl.write_slot(lib, buf[slot * M * 256:(slot + 1) * M * 256], rows, True)
+        back = tl.slot_rows(lib, buf[slot * M * 256:(slot + 1) * M * 256], M, 256, True)
+        assert not bool(torch.isfinite(back[777, 33])), "the Q24 encoding lost the non-finite value"
+        g = torch.zeros(total, dtype=torch.float32, device=dev())
+        work = torch.empty(int(lib.pn_chain_wgrad_work_floats()), dtype=torch.float32, device=dev())
+        arr = (EvalC * 1)(ev)
+        _lib.check(lib.pn_chain_wgrad(1, ctypes.cast(arr, ctypes.c_void_p), nc, 2, g.data_ptr(), work.data_ptr(), work.numel(), 3, 1, 0,
+                                      st()), "pn_chain_wgrad")
+        torch.cuda.synchronize()
+        w3 = g[offs["layers.3.0.weight"]:offs["layers.3.0.weight"] + 65536].view(256, 256)
+        assert not bool(torch.isfinite(w3).all()), (where, "a non-finite operand vanished from the weight gradient")

@@ -33,10 +33,12 @@ def _scene(B, N, seed):
     return rays_c, rgbs[idx], env, env_c, noise
 
 
-@pytest.mark.parametrize("mode,overlap", [("fused_f16x2", False), ("fused_f16x2", True), ("fused_f16x2_t32", False)])
-def test_flat_gradient_at_scale_against_the_oracle_on_identical_gates(mode, overlap):
+# (the default mode at 1024 rays; the fp32-tensor variant and the concurrent weight-gradient schedule at 256 rays: the oracle's
+# fp32 + fp64 forward and backward passes take ~2 minutes of host time per 1024 rays)
+@pytest.mark.parametrize("mode,B,overlap", [("fused_f16x2", 1024, False), ("fused_f16x2_t32", 256, False), ("fused_f16x2", 256, True)])
+def test_flat_gradient_at_scale_against_the_oracle_on_identical_gates(mode, B, overlap):
     import pano_nerf_amd as pn
-    B, N = 1024, 128
+    N = 128
     rays_c, gt_c, env, env_c, noise = _scene(B, N, 1024)
     rays, gt = to_dev(pn.Rays(*rays_c)), gt_c.to(dev())
     model = make_pano(N)
@@ -76,8 +78,8 @@ def test_flat_gradient_at_scale_against_the_oracle_on_identical_gates(mode, over
             ours, theirs = float(np.mean(np.abs(a - c) <= 1e-3 * scale)), float(np.mean(np.abs(b - c) <= 1e-3 * scale))
             assert ours >= min(0.99, theirs - 0.02), (nme, "fraction of elements within 1e-3 of the fp64 run: ours, the fp32 oracle's", ours, theirs)
             assert float(np.median(np.abs(a - c))) <= 2 * float(np.median(np.abs(b - c))) + 1e-6 * scale, (nme, "median error vs fp64")
-            report_worst(f"1024-ray step: fraction of {nme} elements beyond 1e-3 of the fp64 oracle [{mode}]", 1.0 - ours)
-            report_worst(f"1024-ray step: fraction of {nme} elements beyond 1e-3 of the fp64 oracle [the fp32 oracle itself]", 1.0 - theirs)
+            report_worst(f"{B}-ray step: fraction of {nme} elements beyond 1e-3 of the fp64 oracle [{mode}]", 1.0 - ours)
+            report_worst(f"{B}-ray step: fraction of {nme} elements beyond 1e-3 of the fp64 oracle [the fp32 oracle itself]", 1.0 - theirs)
         else:
             assert rel_err(a, b) < 1e-4, (nme, rel_err(a, b))
     # (b) the oracle on the kernels' gate decisions, with its gradient: every output and every gradient entry pointwise
@@ -86,14 +88,40 @@ def test_flat_gradient_at_scale_against_the_oracle_on_identical_gates(mode, over
         ref_loss = orc.pano_loss(refg, rays_c.lossmult, gt_c)
         ref_g = torch.autograd.grad(ref_loss, list(p.values()))
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss)), (float(loss), float(ref_loss))
-    for nme, v, r in zip(NAMES9, outs[1], refg[1]):
+    refg64 = None
+    for i, (nme, v, r) in enumerate(zip(NAMES9, outs[1], refg[1])):
         if v is None:
             continue
         e = rel_err(v.detach().cpu().numpy(), r.detach().numpy())
+        if e >= 1e-4 and nme in LOOSE:
+            # forcing the gates removes the discontinuity, not every ill-conditioning: a ray whose per-sample normals nearly cancel
+            # amplifies fp32 rounding in the fp32 ORACLE too (one element in 3072 at 1.2e-4 here).  Then SURVEY.md 7's third
+            # criterion, on the same gates: error against the fp64 evaluation <= max(1e-4, 2 x the fp32 oracle's own)
+            if refg64 is None:
+                with orc.forced_gates(gate_sets), torch.no_grad():
+                    refg64 = orc.pano_forward(p64, r64, e64, num_samples=N, noise={k: x.double() for k, x in noise.items()})
+            c = refg64[1][i].numpy()
+            ours, theirs = rel_err(v.detach().cpu().numpy(), c), rel_err(r.detach().numpy(), c)
+            assert ours <= max(1e-4, 2 * theirs), (f"l1/{nme} on identical gates vs fp64: ours, the fp32 oracle's own", ours, theirs)
+            report_worst(f"{B}-ray step: {nme} on identical gates vs the fp64 oracle, tensor-scale error [{mode}]", ours)
+            report_worst(f"{B}-ray step: {nme} on identical gates vs the fp64 oracle, tensor-scale error [the fp32 oracle itself]", theirs)
+            continue
         assert e < 1e-4, (f"l1/{nme} on identical gates", e)
     by_name = {k: x.detach().numpy() for k, x in zip(p.keys(), ref_g)}
-    worst = check_flat_grad_pointwise(got, by_name, 5, tol=1e-4)
-    report_worst(f"1024 rays x 128+128 samples: flat gradient vs the oracle on identical gates, worst tensor [{mode}"
+
+    def forced64():
+        # the same gate-forced oracle in fp64: a tensor beyond 1e-4 of the fp32 oracle must be within max(1e-4, 2 x the fp32
+        # oracle's own error) of it (conftest.check_flat_grad_pointwise).  Needed here: layers.0.0.weight of the fp32
+        # oracle is itself 1.7e-4 of the tensor max off its fp64 evaluation on this batch - in both tensor formats alike
+        pp = {k: v.detach().double().requires_grad_(True) for k, v in p.items()}
+        with orc.forced_gates(gate_sets):
+            o64 = orc.pano_forward(pp, r64, e64, num_samples=N, noise={k: x.double() for k, x in noise.items()})
+            l64 = orc.pano_loss(o64, r64.lossmult, gt_c.double())
+            g64 = torch.autograd.grad(l64, list(pp.values()))
+        return {k: x.detach().numpy() for k, x in zip(pp.keys(), g64)}
+
+    worst = check_flat_grad_pointwise(got, by_name, 5, tol=1e-4, ref64_fn=forced64)
+    report_worst(f"{B} rays x 128+128 samples: flat gradient vs the oracle on identical gates, worst tensor [{mode}"
                  f"{', concurrent weight gradients' if overlap else ''}]", worst)
     print(f"gradient at scale {mode} overlap={overlap}: loss {float(loss):.6f} (oracle {float(ref_loss):.6f}), worst tensor {worst:.2e}")
 

@@ -1,10 +1,10 @@
 #!/bin/bash
 # times the chain kernels of the default library and of every variant build found (tools/build_variant.sh <suffix> <flags>),
 # back to back on one box: pano-nerf_amd/libpanonerf_hip[_<suffix>].so
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for f in pano-nerf_amd/libpanonerf_hip.so pano-nerf_amd/libpanonerf_hip_*.so; do
   [ -f $f ] || continue
   echo "== $f"
-  PN_LIB=$f timeout -k 10 120 python3 tools/check_chain.py 2 2>&1 | grep "fused forward"
-  PN_LIB=$f timeout -k 10 120 python3 tools/check_chain_bwd.py 2 2>&1 | grep "fused dgrad\|fused backward\|fused tangent"
+  PN_LIB=$f timeout -k 10 120 python3 tools/experiments/check_chain.py 2 2>&1 | grep "fused forward"
+  PN_LIB=$f timeout -k 10 120 python3 tools/experiments/check_chain_bwd.py 2 2>&1 | grep "fused dgrad\|fused backward\|fused tangent"
 done

@@ -1,6 +1,6 @@
 """Does operand data change GEMM throughput (power-managed clock)?  Same kernels, zero-filled vs N(0,1) operands."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import torch
 from pano_nerf_amd import _lib as lib

@@ -2,7 +2,7 @@
 (argv[1], default 512).  The sub-batches are independent until the gradient sum, so their GEMM chains fill each
 other's first-tile / last-tile bubbles; pano_nerf_amd.concurrent_step is the product form of the 2-stream case."""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
 import numpy as np, torch
 import pano_nerf_amd as pn
 dev = torch.device("cuda:0")

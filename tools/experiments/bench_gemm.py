@@ -1,6 +1,6 @@
 """Micro-benchmark of the two GEMM kernels at the bench shapes (GPU box)."""
 import sys, os, ctypes
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import torch
 from pano_nerf_amd import _lib as lib

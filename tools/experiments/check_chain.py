@@ -16,6 +16,17 @@ E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
 _PLANES = 3
 
 
+
+import os as _os
+_WGS = int(_os.environ.get("PN_MAX_WGS", "0"))  # workgroup budget of every launch (0: all CUs)
+
+
+def _tfmt(planes):
+    """t_format of the calls: PN_TFMT (0 / 1), default Q24 where the build has it"""
+    from pano_nerf_amd import _lib as _l
+    want = int(_os.environ.get("PN_TFMT", "1"))
+    return want if (planes == 2 and int(_l.load().pn_chain_q24_slots(2, 1, 0))) else 0
+
 def TS(t):
     """Flat view of a T tensor in its element type: bf16 with planes = 1 (the buffers are allocated as floats)."""
     if t.dtype == torch.bfloat16:
@@ -31,8 +42,7 @@ def t32_to_rows(t, Mp, F):
 def slot_to_rows(buf, l, Mp, kind):
     """256-wide slot l of tensor `kind` (0 acts, 1 tangents, 2 deltas, 3 reverse sweep), fp32 T layout or Q24 as the mode stores it."""
     from pano_nerf_amd import tlayout
-    lib.pn_chain_q24_slots.argtypes = [__import__("ctypes").c_int] * 2
-    if (int(lib.pn_chain_q24_slots(_PLANES, kind)) >> l) & 1:
+    if (int(lib.pn_chain_q24_slots(_PLANES, _tfmt(_PLANES), kind)) >> l) & 1:
         return tlayout.q24_decode(buf.reshape(-1)[l * Mp * 256:(l + 1) * Mp * 256].view(torch.uint8), Mp, 256)
     return t32_to_rows(TS(buf)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)
 
@@ -72,7 +82,7 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     vtab = E(R * 32)
     call = lambda k=True: _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(),
                                     cov.data_ptr(), vd.data_ptr(), vtab.data_ptr(), enc_t.data_ptr(), acts_t.data_ptr() if (k or keep) else None,
-                                    masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(), None, st())
+                                    masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(), None, _tfmt(planes), _WGS, st())
     call()
     torch.cuda.synchronize()
 

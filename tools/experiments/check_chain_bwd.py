@@ -17,6 +17,17 @@ Z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
 _PLANES = 3
 
 
+
+import os as _os
+_WGS = int(_os.environ.get("PN_MAX_WGS", "0"))  # workgroup budget of every launch (0: all CUs)
+
+
+def _tfmt(planes):
+    """t_format of the calls: PN_TFMT (0 / 1), default Q24 where the build has it"""
+    from pano_nerf_amd import _lib as _l
+    want = int(_os.environ.get("PN_TFMT", "1"))
+    return want if (planes == 2 and int(_l.load().pn_chain_q24_slots(2, 1, 0))) else 0
+
 def TS(t):
     """Flat view of a T tensor in its element type: bf16 with planes = 1 (the buffers are allocated as floats)."""
     if t.dtype == torch.bfloat16:
@@ -32,8 +43,7 @@ def t32_to_rows(t, Mp, F):
 def slot_to_rows(buf, l, Mp, kind):
     """256-wide slot l of tensor `kind` (0 acts, 1 tangents, 2 deltas, 3 reverse sweep), fp32 T layout or Q24 as the mode stores it."""
     from pano_nerf_amd import tlayout
-    lib.pn_chain_q24_slots.argtypes = [__import__("ctypes").c_int] * 2
-    if (int(lib.pn_chain_q24_slots(_PLANES, kind)) >> l) & 1:
+    if (int(lib.pn_chain_q24_slots(_PLANES, _tfmt(_PLANES), kind)) >> l) & 1:
         return tlayout.q24_decode(buf.reshape(-1)[l * Mp * 256:(l + 1) * Mp * 256].view(torch.uint8), Mp, 256)
     return t32_to_rows(TS(buf)[l * Mp * 256:(l + 1) * Mp * 256], Mp, 256)
 
@@ -91,21 +101,21 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     amax = torch.empty(int(lib.pn_chain_amax_slots()), dtype=torch.int32, device=dev)
     _lib.call("pn_chain_forward", M, rows_per_ray, R, nc, planes, pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
               vd.data_ptr(), E(R * 32).data_ptr(), enc_t.data_ptr(), acts_t.data_ptr(), masks_f.data_ptr(), rr2.data_ptr(), rd2.data_ptr(),
-              amax.data_ptr(), st())
+              amax.data_ptr(), _tfmt(planes), _WGS, st())
     rs_t, gmean2 = E(8, Mp * 256), E(M, 3)
     f_dgrad = lambda: _lib.call("pn_chain_density_grad", M, nc, planes, dbias, params.data_ptr(), pack.data_ptr(), mean.data_ptr(),
-                                cov.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(), rs_t.data_ptr(), 1, gmean2.data_ptr(), amax.data_ptr(), st())
+                                cov.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(), rs_t.data_ptr(), 1, gmean2.data_ptr(), amax.data_ptr(), _tfmt(planes), _WGS, st())
     f_dgrad()
     edot_t, tang_t, sdot = E(Mp * 96), E(8, Mp * 256), E(M)
     f_tan = lambda: _lib.call("pn_chain_tangent", M, nc, planes, params.data_ptr(), pack.data_ptr(), mean.data_ptr(), cov.data_ptr(),
-                              masks_f.data_ptr(), v.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), sdot.data_ptr(), amax.data_ptr(), st())
+                              masks_f.data_ptr(), v.data_ptr(), edot_t.data_ptr(), tang_t.data_ptr(), sdot.data_ptr(), amax.data_ptr(), _tfmt(planes), _WGS, st())
     f_tan()
     drgb_t, dhv_t, d8_t, delta_t, coef_t = Z(Mp * 32), E(Mp * 128), Z(Mp * 288), E(8, Mp * 256), Z(Mp * 32)
     d_mean2 = E(M, 3)
     f_bwd = lambda: _lib.call("pn_chain_backward", M, nc, planes, dbias, pack.data_ptr(), masks_f.data_ptr(), rd2.data_ptr(),
                               d_rgb.data_ptr(), d_den.data_ptr(), sdot.data_ptr(), mean.data_ptr(), cov.data_ptr(),
                               drgb_t.data_ptr(), dhv_t.data_ptr(), d8_t.data_ptr(), delta_t.data_ptr(), coef_t.data_ptr(),
-                              d_mean2.data_ptr(), amax.data_ptr(), st())
+                              d_mean2.data_ptr(), amax.data_ptr(), _tfmt(planes), _WGS, st())
     f_bwd()
     torch.cuda.synchronize()
     print(f"M={M} planes={planes}")
@@ -143,9 +153,7 @@ def run(M, rows_per_ray, planes, nc=5, reps=0):
     grads_f = Z(total)
     wfl = int(lib.pn_chain_wgrad_work_floats())
     wk = E(wfl)
-    lib.pn_chain_wgrad.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                   ctypes.c_int64, ctypes.c_void_p]
-    f_wg = lambda: _lib.check(lib.pn_chain_wgrad(1, ctypes.byref(ev), nc, planes, grads_f.data_ptr(), wk.data_ptr(), wfl, st()),
+    f_wg = lambda: _lib.check(lib.pn_chain_wgrad(1, ctypes.byref(ev), nc, planes, grads_f.data_ptr(), wk.data_ptr(), wfl, 3, _tfmt(planes), _WGS, st()),
                               "pn_chain_wgrad")
     f_wg()
     torch.cuda.synchronize()

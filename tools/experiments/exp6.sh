@@ -1,6 +1,6 @@
 #!/bin/bash
 # the training step (bench.py, 10 steps) on the default library and on every variant build, same box
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for f in pano-nerf_amd/libpanonerf_hip.so pano-nerf_amd/libpanonerf_hip_*.so; do
   [ -f $f ] || continue
   echo "== $f"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the training step in the three fused modes on the default library and on every variant build, same box
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for f in pano-nerf_amd/libpanonerf_hip.so pano-nerf_amd/libpanonerf_hip_*.so; do
   [ -f $f ] || continue
   for m in fused_f16x2 fused fused_bf16; do

@@ -1,6 +1,6 @@
 """Run a few launches of each GEMM kernel (for rocprofv3 --pmc)."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
 import torch
 from pano_nerf_amd import _lib as lib
 dev = torch.device("cuda:0"); M = 524288

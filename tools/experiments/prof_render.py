@@ -1,6 +1,6 @@
 """One warm 512x1024 panorama through pano_nerf_amd.render_image (for rocprofv3 --kernel-trace --stats)."""
 import sys, os, time, json
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
 import numpy as np, torch
 import pano_nerf_amd as pn
 dev = torch.device("cuda:0")

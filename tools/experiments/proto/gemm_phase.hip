@@ -5,7 +5,7 @@
 //   SHAPE 0: v_mfma_f32_16x16x32_f16, a step = 2 fragment reads (h, l planes, 1 KB each per wave) + 3 MFMAs of 16 cycles
 //   SHAPE 1: v_mfma_f32_32x32x16_f16, a step = 2 fragment reads + 3 MFMAs of 32 cycles (half the LDS bytes per FLOP)
 // The chunk (24 KB = 12 steps) sits in LDS and is walked `iters` times; accumulators rotate over NT tiles as in chain_gemm.
-// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/proto/gemm_phase.hip -o tools/proto/libgemm_phase.so
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/experiments/proto/gemm_phase.hip -o tools/experiments/proto/libgemm_phase.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>

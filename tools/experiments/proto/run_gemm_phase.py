@@ -1,4 +1,4 @@
-"""Runs tools/proto/gemm_phase.hip: matrix-pipe utilisation of the bare GEMM-phase loop (fragment reads from LDS + three MFMAs per
+"""Runs tools/experiments/proto/gemm_phase.hip: matrix-pipe utilisation of the bare GEMM-phase loop (fragment reads from LDS + three MFMAs per
 step) for the two MFMA shapes and 1 / 2 waves per SIMD."""
 import ctypes, os
 import torch

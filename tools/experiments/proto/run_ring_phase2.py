@@ -1,4 +1,4 @@
-"""Runs tools/proto/ring_phase2.hip: the hand-scheduled GEMM-phase loop plus the pieces of the chains' weight ring, one at a time."""
+"""Runs tools/experiments/proto/ring_phase2.hip: the hand-scheduled GEMM-phase loop plus the pieces of the chains' weight ring, one at a time."""
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))

@@ -1,4 +1,4 @@
-"""Runs tools/proto/ws_layer.hip: correctness of the weight-stationary layer against fp64, then its rate (see the .hip header)."""
+"""Runs tools/experiments/proto/ws_layer.hip: correctness of the weight-stationary layer against fp64, then its rate (see the .hip header)."""
 import ctypes, os, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))

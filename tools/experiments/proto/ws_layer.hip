@@ -6,7 +6,7 @@
 //   weights x 2 planes = 256 registers); per 16-sample tile: fp32 T-layout input [256][16] from global memory (L2-resident in the
 //   pipeline this stands for), per-sample maximum, fp16 pair split ONCE per element into an LDS image of the B operand,
 //   96 MFMAs (16x16x32 f16, three per fp32 product) per wave, bias + ReLU, gate words, fp32 T-layout output.
-// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/proto/ws_layer.hip -o tools/proto/libws_layer.so
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/experiments/proto/ws_layer.hip -o tools/experiments/proto/libws_layer.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -1,6 +1,6 @@
 """Phase stamps of k_gemm_nt_dma workgroups (needs a build with PN_EXTRA=-DPN_TRACE_NT).  100 MHz real-time counter."""
 import os, sys, ctypes
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
 import numpy as np, torch
 from pano_nerf_amd import _lib as lib
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream

@@ -1,9 +1,9 @@
 """Phase times of the 256 x 256 weight-gradient tile on Q24 operands (debug build: tools/build_variant.sh trwg -DPN_TRACE_WG;
-PN_LIB=pano-nerf_amd/libpanonerf_hip_trwg.so python tools/trace_wgrad.py): shader-clock cycles workgroup 0 spent staging (incl. the
+PN_LIB=pano-nerf_amd/libpanonerf_hip_trwg.so python tools/experiments/trace_wgrad.py): shader-clock cycles workgroup 0 spent staging (incl. the
 wait for its loads), at the barrier, issuing the next loads and in the products, per wave, summed over its half blocks."""
 import ctypes, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pano_nerf_amd import _lib
 if os.environ.get("PN_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["PN_LIB"])
