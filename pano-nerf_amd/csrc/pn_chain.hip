@@ -37,6 +37,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1871,6 +1872,15 @@ struct WgArgs {
     int64_t slab_stride;
     int bias;
 };
+// ONE launch runs up to WG_MAXJ jobs of the same tile configuration and operand format (grid.y = job): the six 256 x 256 trunk
+// layers whose operands are both Q24, or layer 0 and the skip columns of layer 5.  Every job gets 1 / n of the CUs and n times the
+// sample range per workgroup: the same parallelism with 1 / n of the launches, of the slab bytes (a workgroup writes its 257 KB of
+// partial sums once per n times as many half blocks) and of the slab reductions - a job costs ~40 us whatever its size (prologue,
+// slab write, reduction launch), 18 % of the 512-ray step in fifteen separate launches.
+constexpr int WG_MAXJ = 8;
+struct WgMulti {
+    WgArgs job[WG_MAXJ];
+};
 
 template <int NP>
 __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<NP>& b, f32x16 v) {
@@ -1898,7 +1908,8 @@ __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<N
 // image then holds feature f in row (f & ~3) | ((f + (f >> 2)) & 3): a unit's four writes go to rows 4 qb + f for a fixed f across
 // the wave, which in the plain image are 128 bytes apart - the same eight banks sixteen times.
 template <int NP, int TM, int TN, int WM, int WN, bool X24 = false, bool Y24 = false>
-__global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
+    const WgArgs& a = multi.job[blockIdx.y];
     static_assert(!(X24 || Y24) || (NP == 2 && TILE == 16), "Q24 tensors exist in fp16-pair builds with 16-sample tiles");
     static_assert(!X24 || Y24, "combinations in use: (0,0), (0,1), (1,1)");
     constexpr bool ROT = X24 || Y24;  // row permutation of the LDS images
@@ -1918,6 +1929,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int64_t h0 = (int64_t)blockIdx.x * a.per;
+    if (h0 >= a.half_total) return;  // (uniform: a job of a multi-job launch with fewer workgroups than grid.x; no slab of its own)
     int64_t h1 = h0 + a.per;
     if (h1 > a.half_total) h1 = a.half_total;
 
@@ -2544,12 +2556,26 @@ struct WgJob {
 static const int kCfgM[5] = {256, 256, 128, 32, 32};
 static const int kCfgN[5] = {256, 96, 288, 256, 128};
 
-// Slab reduction of one job in ONE launch: dst[r][c] += sum over the nb slabs of their [rows x cols] part (leading dimension
-// src_ld), and dbias[i] += sum of the slabs' row sums (at slab offset bias_off), in a fixed order (64 elements per workgroup,
-// four partial sums each, eight loads in flight): 31 reduction launches per training step were 16 % of its launches at the
-// 512-ray share.
-__global__ __launch_bounds__(256) void k_reduce_job(const float* slabs, int64_t nb, int64_t stride, int rows, int cols, int src_ld,
-                                                     float* dst, int ldd, int64_t bias_off, float* dbias) {
+// Slab reduction of the jobs of one launch (grid.y = job): dst[r][c] += sum over the job's nb slabs of their [rows x cols] part
+// (leading dimension src_ld), and dbias[i] += sum of the slabs' row sums (at slab offset bias_off), in a fixed order (64 elements per
+// workgroup, four partial sums each, eight loads in flight): 31 reduction launches per training step were 16 % of its launches at
+// the 512-ray share.
+struct RedJob {
+    const float* slabs;
+    int64_t nb, stride, bias_off;
+    int rows, cols, src_ld, ldd;
+    float* dst;
+    float* dbias;
+};
+struct RedMulti {
+    RedJob job[WG_MAXJ];
+};
+__global__ __launch_bounds__(256) void k_reduce_job(RedMulti multi) {
+    const RedJob& J = multi.job[blockIdx.y];
+    const float* slabs = J.slabs;
+    const int64_t nb = J.nb, stride = J.stride;
+    const int rows = J.rows, cols = J.cols;
+    float* dbias = J.dbias;
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + tx, nw = rows * cols, n = nw + (dbias ? rows : 0);
@@ -2559,10 +2585,10 @@ __global__ __launch_bounds__(256) void k_reduce_job(const float* slabs, int64_t 
         const float* p;
         if (e < nw) {
             const int r = e / cols, c = e - r * cols;
-            p = slabs + (int64_t)r * src_ld + c;
-            d = dst + (int64_t)r * ldd + c;
+            p = slabs + (int64_t)r * J.src_ld + c;
+            d = J.dst + (int64_t)r * J.ldd + c;
         } else {
-            p = slabs + bias_off + (e - nw);
+            p = slabs + J.bias_off + (e - nw);
             d = dbias + (e - nw);
         }
         int64_t b = ty;
@@ -2585,38 +2611,58 @@ __global__ __launch_bounds__(256) void k_reduce_job(const float* slabs, int64_t 
     if (ty == 0 && e < n) *d += (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
+// jobs [j0, j0 + nj) of `jobs`: same tile configuration and operand format, disjoint destinations -> one GEMM launch + one reduction
 template <int NP>
-static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, int max_wgs, hipStream_t s) {
-    WgArgs a{};
-    int64_t total = 0;
-    for (int i = 0; i < j.nseg; ++i) {
-        a.seg[i] = j.seg[i];
-        total += j.seg[i].nhalf;
-    }
-    a.nseg = j.nseg;
-    a.half_total = total;
-    const int TMW = kCfgM[j.cfg], TNW = kCfgN[j.cfg];
+static int run_wgrad_group(const WgJob* jobs, int nj, float* work, int64_t work_floats, int max_wgs, hipStream_t s) {
+    if (nj < 1 || nj > WG_MAXJ) return PN_ERR_BAD_SHAPE;
+    const WgJob& j0 = jobs[0];
+    const int TMW = kCfgM[j0.cfg], TNW = kCfgN[j0.cfg];
     const int64_t stride = (int64_t)TMW * TNW + TMW;
     // workgroups per CU the configuration's registers and LDS allow (the narrow tiles: 146 / 100 registers per lane,
     // 37 / 20 KB): more sample ranges in flight, their staging and product phases interleave
     static const int kPerCu[5] = {1, 1, 1, 3, 4};
     int cus = chain_cus();
-    if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;  // the CUs this job may occupy (the rest run a chain kernel of another stream)
-    int64_t nsplit = (int64_t)cus * kPerCu[j.cfg];
-    if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;  // at least four half blocks per workgroup
-    if (nsplit < 1) nsplit = 1;
-    a.per = (total + nsplit - 1) / nsplit;
-    nsplit = (total + a.per - 1) / a.per;
-    if (nsplit * stride + 64 * stride > work_floats) return PN_ERR_BAD_SHAPE;
-    a.slab = work;
-    a.slab_stride = stride;
-    a.bias = j.dbias != nullptr;
-    const dim3 grid((unsigned)nsplit);
-    double rows = 0;
-    for (int i = 0; i < j.nseg; ++i) rows += 16.0 * (double)j.seg[i].nhalf;
+    if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;  // the CUs this launch may occupy (the rest run a chain kernel of another stream)
+    const int64_t slots = (int64_t)cus * kPerCu[j0.cfg] / nj;  // workgroups per job
+    WgMulti m{};
+    RedMulti r{};
+    int64_t nsplit_max = 0, slab0 = 0;
+    double flops = 0;
+    for (int q = 0; q < nj; ++q) {
+        const WgJob& j = jobs[q];
+        if (j.cfg != j0.cfg || j.fmt != j0.fmt) return PN_ERR_BAD_SHAPE;
+        WgArgs& a = m.job[q];
+        int64_t total = 0;
+        for (int i = 0; i < j.nseg; ++i) {
+            a.seg[i] = j.seg[i];
+            total += j.seg[i].nhalf;
+        }
+        a.nseg = j.nseg;
+        a.half_total = total;
+        int64_t nsplit = slots < 1 ? 1 : slots;
+        if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;  // at least four half blocks per workgroup
+        if (nsplit < 1) nsplit = 1;
+        a.per = (total + nsplit - 1) / nsplit;
+        nsplit = (total + a.per - 1) / a.per;
+        a.slab = work + slab0 * stride;
+        a.slab_stride = stride;
+        a.bias = j.dbias != nullptr;
+        r.job[q] = RedJob{a.slab, nsplit, stride, (int64_t)TMW * TNW, j.rows, j.cols, TNW, j.ldd, j.dst, j.dbias};
+        slab0 += nsplit;
+        nsplit_max = nsplit > nsplit_max ? nsplit : nsplit_max;
+        double rows = 0;
+        for (int i = 0; i < j.nseg; ++i) rows += 16.0 * (double)j.seg[i].nhalf;
+        flops += 2.0 * rows * j.rows * j.cols;
+    }
+    if ((slab0 + 64) * stride > work_floats) return PN_ERR_BAD_SHAPE;
+    // (a job with fewer workgroups than grid.x: its surplus workgroups find h0 >= half_total and write a zero slab that the
+    // reduction does not read - nsplit is the job's own)
+    const dim3 grid((unsigned)nsplit_max, (unsigned)nj);
+    const WgJob& j = j0;
+    const WgMulti& a = m;
     {
     // (class per kernel instantiation: 6 + cfg; the Q24 forms of the 256 x 256 tile are 11 (Y in Q24) and 12 (X and Y in Q24))
-    PnProfScope prof((j.cfg == 0 && j.fmt) ? (j.fmt == 3 ? 12 : 11) : 6 + j.cfg, 2.0 * rows * j.rows * j.cols, s);  // the GEMM kernel alone
+    PnProfScope prof((j.cfg == 0 && j.fmt) ? (j.fmt == 3 ? 12 : 11) : 6 + j.cfg, flops, s);  // the GEMM kernel alone
     switch (j.cfg) {
         case 0:
             if constexpr (kQ24<NP>) {
@@ -2635,9 +2681,12 @@ static int run_wgrad_job(const WgJob& j, float* work, int64_t work_floats, int m
     }
     }
     PN_CHECK_LAUNCH();
-    const int n = j.rows * j.cols + (j.dbias ? j.rows : 0);
-    hipLaunchKernelGGL(k_reduce_job, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, work, nsplit, stride, j.rows, j.cols, TNW,
-                       j.dst, j.ldd, (int64_t)TMW * TNW, j.dbias);
+    int nmax = 0;
+    for (int q = 0; q < nj; ++q) {
+        const int n = jobs[q].rows * jobs[q].cols + (jobs[q].dbias ? jobs[q].rows : 0);
+        nmax = n > nmax ? n : nmax;
+    }
+    hipLaunchKernelGGL(k_reduce_job, dim3((unsigned)((nmax + 63) / 64), (unsigned)nj), dim3(256), 0, s, r);
     PN_CHECK_LAUNCH();
     return PN_OK;
 }
@@ -2826,11 +2875,16 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     if (!first && !n2) return PN_OK;  // second-order rows only, and no evaluation has any
     // planes = 2: a weight gradient sums over ALL samples, so each operand tensor gets ONE power of two, from the maxima
     // the chain kernels left in the evaluation's table
-    auto run = [&](const WgJob& j) {
-        if (!j.nseg) return (int)PN_OK;
-        return planes == 3 ? run_wgrad_job<3>(j, work, work_floats, max_wgs, s)
-                           : (planes == 2 ? run_wgrad_job<2>(j, work, work_floats, max_wgs, s)
-                                          : run_wgrad_job<1>(j, work, work_floats, max_wgs, s));
+    // the step's jobs are collected first and launched in groups of the same tile configuration and operand format (see WgMulti);
+    // `after`: a job that adds into the destination of an earlier one (the softplus' row of the density head) goes in a later launch
+    std::vector<WgJob> jobs;
+    std::vector<int> after;
+    auto run = [&](const WgJob& j, int later = 0) {
+        if (j.nseg) {
+            jobs.push_back(j);
+            after.push_back(later);
+        }
+        return (int)PN_OK;
     };
     auto am = [&](int e, int slot) -> const uint32_t* { return ev[e].amax ? ev[e].amax + slot : nullptr; };
     auto mp = [&](int e) { return pn_pad(ev[e].M); };
@@ -2896,7 +2950,7 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
                                        am(e, AM_COEF), am(e, AM_TANG0 + 7)};
         if (k.nseg) {
             k.cfg = 3; k.rows = 1; k.cols = 256; k.dst = grads + L.wd; k.ldd = 256; k.dbias = nullptr;
-            if ((rc = run(k)) != PN_OK) return rc;
+            if ((rc = run(k, 1)) != PN_OK) return rc;
         }
     }
     if (first) {  // view layer: d hv^T [bottleneck | view encoding]
@@ -2911,6 +2965,33 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
         for (int e = 0; e < n; ++e) j.seg[j.nseg++] = WSeg{ev[e].drgb_t, act(e, 9), mp(e) / 16, 32, 128, 1, am(e, AM_DRGB), am(e, AM_ACT0 + 9)};
         j.cfg = 4; j.rows = 3; j.cols = 128; j.dst = grads + L.wc; j.ldd = 128; j.dbias = grads + L.bc;
         if ((rc = run(j)) != PN_OK) return rc;
+    }
+    // Jobs share a launch only as far as a workgroup's range stays within WG_RANGE half blocks (8192 samples: what one job alone
+    // gives a workgroup at the 4096-ray batch).  Sharing pays where the jobs are short - the 512-ray share of an 8-GPU run: 3.36 ->
+    // 3.22 - 3.27 ms per step, nothing at 4096 rays (profiles/r04_multijob_ab.txt) - and a range n times as long is an n times
+    // longer fp32 accumulation chain per accumulator: on the cancelling-sum stress test (1.97 M rows, fp32 tensors, seven jobs in
+    // one launch) the error grew from 1.9e-6 to 7.4e-6 of the tensor's largest element (an fp32 GEMM: 1.5e-5).
+    constexpr int64_t WG_RANGE = 512;
+    std::vector<char> done(jobs.size(), 0);
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        if (done[i]) continue;
+        WgJob grp[WG_MAXJ];
+        int ng = 0;
+        int64_t total_i = 0;
+        for (int q = 0; q < jobs[i].nseg; ++q) total_i += jobs[i].seg[q].nhalf;
+        int cus_i = chain_cus();
+        if (max_wgs > 0 && max_wgs < cus_i) cus_i = max_wgs;
+        int64_t gmax = WG_RANGE * cus_i / (total_i > 0 ? total_i : 1);
+        gmax = gmax < 1 ? 1 : (gmax > WG_MAXJ ? WG_MAXJ : gmax);
+        for (size_t k = i; k < jobs.size() && ng < gmax; ++k)
+            if (!done[k] && jobs[k].cfg == jobs[i].cfg && jobs[k].fmt == jobs[i].fmt && after[k] == after[i]) {
+                grp[ng++] = jobs[k];
+                done[k] = 1;
+            }
+        rc = planes == 3 ? run_wgrad_group<3>(grp, ng, work, work_floats, max_wgs, s)
+                         : (planes == 2 ? run_wgrad_group<2>(grp, ng, work, work_floats, max_wgs, s)
+                                        : run_wgrad_group<1>(grp, ng, work, work_floats, max_wgs, s));
+        if (rc != PN_OK) return rc;
     }
     return PN_OK;
 }
