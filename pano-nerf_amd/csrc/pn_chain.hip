@@ -184,7 +184,7 @@ struct PackLayer {
     int64_t aux_off;  // floats copied to the aux KB of the layer's LAST chunk (bias, added when the sum is complete); < 0: zeros
     int aux_n;
 };
-#define PACK_MAXL 16
+#define PACK_MAXL 32  // both directions in one table (F_COUNT + B_COUNT = 25 GEMMs)
 struct PackTable {
     PackLayer L[PACK_MAXL];
     int n, nchunks;
@@ -203,20 +203,14 @@ __device__ __forceinline__ int scale_exp(float amax, int cap = EXP_CAP) {
     const int e = EXP_TOP - __builtin_amdgcn_frexp_expf(amax);
     return e > cap ? cap : e;
 }
-// Clears a small table of words.  A kernel, not hipMemsetAsync - a WORKAROUND: with 256-byte memset nodes a replayed HIP
-// graph gave NaN or stale-scale steps in 4 of 14 runs of the 512-ray bench (never with eager launches), although the
-// captured graph is a single linear chain in which every memset node has the kernel before it as predecessor and the
-// accumulating kernel as successor (hipGraphGetEdges on the pre-fix tree: profiles/r03_graph_memset_nodes.txt): not a
-// missing dependency, but how replayed memset nodes execute on this runtime (ROCm 7.2).
-__global__ void k_chain_clear(uint32_t* p, int n) {
-    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
-}
-static int chain_clear(void* p, int words, hipStream_t s) {
-    hipLaunchKernelGGL(k_chain_clear, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(p), words);
-    PN_CHECK_LAUNCH();
-    return PN_OK;
-}
+// Small tables that a training step accumulates into (the per-evaluation tensor maxima) are cleared by a KERNEL (k_view_table's first
+// workgroup), not by hipMemsetAsync - a WORKAROUND: with 256-byte memset nodes a replayed HIP graph gave NaN or stale-scale steps in 4
+// of 14 runs of the 512-ray bench (never with eager launches), although the captured graph is a single linear chain in which every
+// memset node has the kernel before it as predecessor and the accumulating kernel as successor (hipGraphGetEdges on the pre-fix
+// tree: profiles/r03_graph_memset_nodes.txt): not a missing dependency, but how replayed memset nodes execute on this runtime
+// (ROCm 7.2).  The weight maxima need no clear at all any more: every slice of k_chain_wexp writes its own word.
 constexpr int WEXP_SLICES = 16;  // workgroups per GEMM of the table (one alone took 67 us on the transposed 256 x 352 matrix)
+// every slice WRITES its own maximum (wmax[GEMM * WEXP_SLICES + slice]; k_chain_pack takes the largest): no table to clear, no atomics
 __global__ void k_chain_wexp(PackTable tab, const float* params, uint32_t* wmax) {
     const PackLayer& L = tab.L[blockIdx.x];
     float m = 0.f;
@@ -237,10 +231,10 @@ __global__ void k_chain_wexp(PackTable tab, const float* params, uint32_t* wmax)
         if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(wmax + blockIdx.x, __float_as_uint(red[0]));
+    if (threadIdx.x == 0) wmax[blockIdx.x * WEXP_SLICES + blockIdx.y] = __float_as_uint(red[0]);
 }
 
-// wexp: [0, 32) the exponents the chain kernels read (written here), [32, 64) the maxima k_chain_wexp gathered
+// wexp: [0, 32) the exponents the chain kernels read (written here), then WEXP_SLICES maxima per GEMM from k_chain_wexp
 template <int NP>
 __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* out, int* wexp) {
     constexpr int CF = Cfg<NP>::CF, SLOT = Cfg<NP>::SLOT, PER = Cfg<NP>::PER;
@@ -266,7 +260,11 @@ __global__ void k_chain_pack(PackTable tab, const float* params, unsigned char* 
     const int step = (chunk - L.chunk0) * PER + f / NP;  // k-step major, tile minor
     int wex = 0;
     if constexpr (NP == 2) {
-        wex = scale_exp(__uint_as_float(reinterpret_cast<const uint32_t*>(wexp)[32 + li]), EXP_CAP_W);
+        const uint32_t* wm = reinterpret_cast<const uint32_t*>(wexp) + 32 + li * WEXP_SLICES;
+        uint32_t top = 0u;  // (non-negative floats order as unsigned integers)
+#pragma unroll
+        for (int sl = 0; sl < WEXP_SLICES; ++sl) top = wm[sl] > top ? wm[sl] : top;
+        wex = scale_exp(__uint_as_float(top), EXP_CAP_W);
         if (chunk == L.chunk0 && f == 0 && lane == 0) wexp[li] = wex;
     }
     unsigned short o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1243,7 +1241,10 @@ __device__ __forceinline__ Ex finish_gated(accv (&acc)[NT_H], const Gate& m, typ
 
 // pos_enc of the view directions (models/mip.py:431-441: [x | sin(x 2^l) | sin(x 2^l + pi/2)], l < 4) per view row, padded to
 // 32 features: feature v < 3 is the direction, 3 <= v < 27 the sines, the rest zero.
-__global__ void k_view_table(int64_t view_rows, const float* viewdirs, float* tab) {
+// The first workgroup also clears the evaluation's table of tensor maxima (`amax`, `amax_n` <= 256 words; null: none): one launch
+// in front of the forward chain instead of two.
+__global__ void k_view_table(int64_t view_rows, const float* viewdirs, float* tab, uint32_t* amax, int amax_n) {
+    if (amax && blockIdx.x == 0 && (int)threadIdx.x < amax_n) amax[threadIdx.x] = 0u;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= view_rows * 32) return;
     const int64_t r = idx >> 5;
@@ -1902,6 +1903,19 @@ __device__ __forceinline__ f32x16 mfma_split32(const BFrag<NP>& a, const BFrag<N
 }
 // the T tensors are read once per GEMM: non-temporal loads (4.70 -> 4.57 ms for the GEMMs of one evaluation)
 #define WG_LD(p) __builtin_nontemporal_load(p)
+// The three 16-byte loads of a Q24 unit (48 bytes, stride 48 across the lanes): each instruction touches a third of every 128-byte
+// line of the wave's 3 KB.  As NON-temporal loads each of the three fetched its lines from L2 on its own - TCP_TCC_READ_REQ 7.63e7 per
+// launch of the 256 x 256 tile against 2.57e7 TCC_EA0_RDREQ, two L2 hits per miss; as plain loads the second and third hit the lines
+// the first brought into the vector L1: 2.52e7 requests, no L2 hits (profiles/r04_wgrad_unit_loads.txt).  The kernel itself is no
+// faster (761 us under the counters either way: it is not bound by L2 requests), the training step 0.65 % (same box, twice).
+#ifndef PN_WG_UNIT_NT
+#define PN_WG_UNIT_NT 0
+#endif
+#if PN_WG_UNIT_NT
+#define WG_LDU(p) __builtin_nontemporal_load(p)
+#else
+#define WG_LDU(p) (*(p))
+#endif
 // Y24 / X24: the operand tensor is stored in Q24 (see pack_q24): its work item is a UNIT of 48 contiguous bytes - four features of
 // four samples - unpacked to fp32 (one byte permute per element) and transposed in registers into four (feature, 4 samples) pieces.
 // With both operands in Q24 the X and Y units form one list over the threads (one unit per thread on the 256 x 256 tile).  The LDS
@@ -2045,9 +2059,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
                 const int u = unit_of(i);
                 if ((UX + UY) % NTH == 0 || u < UX + UY) {
                     const f32x4* p = reinterpret_cast<const f32x4*>(u < UX ? xq + u * 48 : yq + (u - UX) * 48);  // (wave-uniform)
-                    ur[set][i][0] = WG_LD(p);
-                    ur[set][i][1] = WG_LD(p + 1);
-                    ur[set][i][2] = WG_LD(p + 2);
+                    ur[set][i][0] = WG_LDU(p);
+                    ur[set][i][1] = WG_LDU(p + 1);
+                    ur[set][i][2] = WG_LDU(p + 2);
                 }
             }
         }
@@ -2438,11 +2452,24 @@ static PackTable bwd_table(int nc) {
 // the packed blob: [forward chain | backward chain | int wexp[F_COUNT + B_COUNT] (NP = 2; 256 bytes)]
 template <int NP>
 static constexpr int64_t chain_bytes() { return (int64_t)(fwd_chunk0<NP>(F_COUNT) + bwd_chunk0<NP>(B_COUNT)) * Cfg<NP>::SLOT; }
-constexpr int64_t WEXP_BYTES = 256;
-static_assert(F_COUNT + B_COUNT <= 32, "wexp table: 32 exponents + 32 maxima");
+constexpr int64_t WEXP_BYTES = 4 * (32 + 32 * WEXP_SLICES);
+static_assert(F_COUNT + B_COUNT <= 32, "wexp table: 32 exponents + 32 x WEXP_SLICES maxima");
 static_assert(F_COUNT <= 16 && B_COUNT <= 16, "the chain kernels keep a direction's exponents in lanes 0..15");
+// Both directions as ONE table: the backward chain's chunks follow the forward chain's in the blob, its GEMMs follow in the
+// exponent table - one maxima launch (NP = 2) and one pack launch per training step (five launches before: a clear and two
+// each, 50 us of the 512-ray step).
 template <int NP>
-static int pack_chain(const PackTable& T, const float* params, unsigned char* out, int* wexp, hipStream_t s) {
+static int pack_both(int nc, const float* params, unsigned char* out, hipStream_t s) {
+    int* wexp = reinterpret_cast<int*>(out + chain_bytes<NP>());
+    PackTable T = fwd_table<NP>(nc);
+    const PackTable B = bwd_table<NP>(nc);
+    static_assert(F_COUNT + B_COUNT <= PACK_MAXL, "one table for both directions");
+    for (int i = 0; i < B.n; ++i) {
+        T.L[T.n + i] = B.L[i];
+        T.L[T.n + i].chunk0 += T.nchunks;
+    }
+    T.n += B.n;
+    T.nchunks += B.nchunks;
     if (NP == 2) {
         hipLaunchKernelGGL(k_chain_wexp, dim3(T.n, WEXP_SLICES), dim3(256), 0, s, T, params, reinterpret_cast<uint32_t*>(wexp) + 32);
         PN_CHECK_LAUNCH();
@@ -2451,15 +2478,6 @@ static int pack_chain(const PackTable& T, const float* params, unsigned char* ou
     hipLaunchKernelGGL(k_chain_pack<NP>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, T, params, out, wexp);
     PN_CHECK_LAUNCH();
     return PN_OK;
-}
-template <int NP>
-static int pack_both(int nc, const float* params, unsigned char* out, hipStream_t s) {
-    int* wexp = reinterpret_cast<int*>(out + chain_bytes<NP>());
-    int rc = chain_clear(wexp, (int)(WEXP_BYTES / 4), s);  // (maxima start at 0; NP != 2: unused)
-    if (rc != PN_OK) return rc;
-    rc = pack_chain<NP>(fwd_table<NP>(nc), params, out, wexp, s);
-    if (rc != PN_OK) return rc;
-    return pack_chain<NP>(bwd_table<NP>(nc), params, out + (int64_t)fwd_chunk0<NP>(F_COUNT) * Cfg<NP>::SLOT, wexp + F_COUNT, s);
 }
 
 // Per-device launch state: the chains need Cfg<NP>::LDS_BYTES of dynamic LDS (the ring: 5 slots x 25 KB = 125 KB with fp16 pairs
@@ -2567,8 +2585,9 @@ struct RedJob {
     float* dst;
     float* dbias;
 };
+constexpr int RED_MAXJ = WG_MAXJ;
 struct RedMulti {
-    RedJob job[WG_MAXJ];
+    RedJob job[RED_MAXJ];
 };
 __global__ __launch_bounds__(256) void k_reduce_job(RedMulti multi) {
     const RedJob& J = multi.job[blockIdx.y];
@@ -2579,6 +2598,7 @@ __global__ __launch_bounds__(256) void k_reduce_job(RedMulti multi) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + tx, nw = rows * cols, n = nw + (dbias ? rows : 0);
+    if (blockIdx.x * 64 >= n) return;  // (uniform: a smaller job of the launch)
     float acc = 0.f;
     float* d = nullptr;
     if (e < n) {
@@ -2612,8 +2632,14 @@ __global__ __launch_bounds__(256) void k_reduce_job(RedMulti multi) {
 }
 
 // jobs [j0, j0 + nj) of `jobs`: same tile configuration and operand format, disjoint destinations -> one GEMM launch + one reduction
+static int run_reduce(const std::vector<RedJob>& red, size_t i0, size_t i1, hipStream_t s);
+// (One reduction launch per group, the workspace reused by the next group.  Keeping every group's slabs until ONE reduction launch
+// at the end of the step - thirteen launches fewer, 0.9 GB of workspace - measured no gain, eager or replayed:
+// profiles/r04_launch_merge_ab.txt.)
 template <int NP>
 static int run_wgrad_group(const WgJob* jobs, int nj, float* work, int64_t work_floats, int max_wgs, hipStream_t s) {
+    int64_t used = 0;
+    std::vector<RedJob> red;
     if (nj < 1 || nj > WG_MAXJ) return PN_ERR_BAD_SHAPE;
     const WgJob& j0 = jobs[0];
     const int TMW = kCfgM[j0.cfg], TNW = kCfgN[j0.cfg];
@@ -2625,8 +2651,8 @@ static int run_wgrad_group(const WgJob* jobs, int nj, float* work, int64_t work_
     if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;  // the CUs this launch may occupy (the rest run a chain kernel of another stream)
     const int64_t slots = (int64_t)cus * kPerCu[j0.cfg] / nj;  // workgroups per job
     WgMulti m{};
-    RedMulti r{};
     int64_t nsplit_max = 0, slab0 = 0;
+    float* const base = work + used;
     double flops = 0;
     for (int q = 0; q < nj; ++q) {
         const WgJob& j = jobs[q];
@@ -2644,17 +2670,18 @@ static int run_wgrad_group(const WgJob* jobs, int nj, float* work, int64_t work_
         if (nsplit < 1) nsplit = 1;
         a.per = (total + nsplit - 1) / nsplit;
         nsplit = (total + a.per - 1) / a.per;
-        a.slab = work + slab0 * stride;
+        a.slab = base + slab0 * stride;
         a.slab_stride = stride;
         a.bias = j.dbias != nullptr;
-        r.job[q] = RedJob{a.slab, nsplit, stride, (int64_t)TMW * TNW, j.rows, j.cols, TNW, j.ldd, j.dst, j.dbias};
+        red.push_back(RedJob{a.slab, nsplit, stride, (int64_t)TMW * TNW, j.rows, j.cols, TNW, j.ldd, j.dst, j.dbias});
         slab0 += nsplit;
         nsplit_max = nsplit > nsplit_max ? nsplit : nsplit_max;
         double rows = 0;
         for (int i = 0; i < j.nseg; ++i) rows += 16.0 * (double)j.seg[i].nhalf;
         flops += 2.0 * rows * j.rows * j.cols;
     }
-    if ((slab0 + 64) * stride > work_floats) return PN_ERR_BAD_SHAPE;
+    if (used + slab0 * stride > work_floats) return PN_ERR_BAD_SHAPE;
+    used += slab0 * stride;
     // (a job with fewer workgroups than grid.x: its surplus workgroups find h0 >= half_total and write a zero slab that the
     // reduction does not read - nsplit is the job's own)
     const dim3 grid((unsigned)nsplit_max, (unsigned)nj);
@@ -2681,13 +2708,23 @@ static int run_wgrad_group(const WgJob* jobs, int nj, float* work, int64_t work_
     }
     }
     PN_CHECK_LAUNCH();
-    int nmax = 0;
-    for (int q = 0; q < nj; ++q) {
-        const int n = jobs[q].rows * jobs[q].cols + (jobs[q].dbias ? jobs[q].rows : 0);
-        nmax = n > nmax ? n : nmax;
+    return run_reduce(red, 0, red.size(), s);
+}
+// the slab reductions of jobs [i0, i1) in one launch
+static int run_reduce(const std::vector<RedJob>& red, size_t i0, size_t i1, hipStream_t s) {
+    while (i0 < i1) {
+        const size_t n = i1 - i0 < (size_t)RED_MAXJ ? i1 - i0 : (size_t)RED_MAXJ;
+        RedMulti r{};
+        int nmax = 0;
+        for (size_t q = 0; q < n; ++q) {
+            r.job[q] = red[i0 + q];
+            const int e = r.job[q].rows * r.job[q].cols + (r.job[q].dbias ? r.job[q].rows : 0);
+            nmax = e > nmax ? e : nmax;
+        }
+        hipLaunchKernelGGL(k_reduce_job, dim3((unsigned)((nmax + 63) / 64), (unsigned)n), dim3(256), 0, s, r);
+        PN_CHECK_LAUNCH();
+        i0 += n;
     }
-    hipLaunchKernelGGL(k_reduce_job, dim3((unsigned)((nmax + 63) / 64), (unsigned)nj), dim3(256), 0, s, r);
-    PN_CHECK_LAUNCH();
     return PN_OK;
 }
 
@@ -2748,16 +2785,13 @@ int pn_chain_forward(int64_t M, int rows_per_ray, int64_t view_rows, int nc, int
     a.pack = (const unsigned char*)pack;
     a.wexp = reinterpret_cast<const int*>(a.pack + g.bytes);
     a.mean = mean; a.cov = cov; a.viewdirs = viewdirs; a.view_tab = view_tab;
-    hipLaunchKernelGGL(k_view_table, dim3((unsigned)((view_rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, view_rows,
-                       viewdirs, view_tab);
-    PN_CHECK_LAUNCH();
     a.enc_t = enc_t; a.acts_t = acts_t; a.masks = masks; a.raw_rgb = raw_rgb; a.raw_den = raw_den;
     a.amax = planes == 2 ? amax : nullptr;
     a.q24 = t_format;
-    if (a.amax) {
-        const int rc = chain_clear(a.amax, AM_COUNT, (hipStream_t)stream);
-        if (rc != PN_OK) return rc;
-    }
+    static_assert(AM_COUNT <= 256, "k_view_table's first workgroup clears the table of maxima");
+    hipLaunchKernelGGL(k_view_table, dim3((unsigned)((view_rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, view_rows,
+                       viewdirs, view_tab, a.amax, AM_COUNT);
+    PN_CHECK_LAUNCH();
     LAUNCH_CHAIN(k_chain_fwd, planes, a.nst, max_wgs, a, (hipStream_t)stream, 2, (double)M * flops_mlp(nc));
 }
 
@@ -2844,6 +2878,8 @@ int pn_chain_backward(int64_t M, int nc, int planes, float density_bias, const v
 
 
 int64_t pn_chain_wgrad_work_floats(void) {
+    // the partial sums of one launch (a group of jobs of one tile configuration): (workgroups) x (tile + row sums) floats, the
+    // largest being one 256 x 256 slab per CU; sized for up to 320 CUs
     const int64_t stride = 256 * 288 + 256;
     return (256 + 64) * stride + 1024;
 }
@@ -2973,8 +3009,9 @@ int pn_chain_wgrad(int n, const PnChainEval* ev, int nc, int planes, float* grad
     // one launch) the error grew from 1.9e-6 to 7.4e-6 of the tensor's largest element (an fp32 GEMM: 1.5e-5).
     constexpr int64_t WG_RANGE = 512;
     std::vector<char> done(jobs.size(), 0);
+    for (int pass = 0; pass < 2; ++pass)
     for (size_t i = 0; i < jobs.size(); ++i) {
-        if (done[i]) continue;
+        if (done[i] || after[i] != pass) continue;
         WgJob grp[WG_MAXJ];
         int ng = 0;
         int64_t total_i = 0;
