@@ -418,7 +418,7 @@ def main():
         top = roof_mfma  # the dominant kernel is actually nearer to (the 256 x 256 weight-gradient tile: HBM)
         nearer = "hbm" if (roof_hbm is not None and roof_hbm["frac"] > roof_mfma["frac"]) else "mfma"
         traffic, pmc_tab, pmc_src = None, {}, None
-        for cand in (["r03_pmc_summary.json", "r02_pmc_summary.json"] if fused else ["r01_pmc_summary.json"]):
+        for cand in (["r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"] if fused else ["r01_pmc_summary.json"]):
             pmc = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc):
                 try:

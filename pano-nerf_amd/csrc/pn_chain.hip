@@ -37,7 +37,19 @@
 #include <string.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include <vector>
+
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant expression
+// in the body (immediate operands of inline asm)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1938,7 +1950,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
     constexpr int UX = X24 ? TMW : 0, UY = Y24 ? TNW : 0;               // Q24 units per half block
     constexpr int LU = (UX + UY + NTH - 1) / NTH;                       // units per thread (X units first, then Y units)
     static_assert(UX % 64 == 0, "a wave's units are all X or all Y");
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+    // Q24 units: a wave LOADS its 64 units (3 KB contiguous) as three fully coalesced 1-KB instructions - lane i takes the 16-byte
+    // pieces i, i + 64, i + 128 of the chunk - and turns pieces into units (unit i = pieces 3 i .. 3 i + 2) through a wave-private
+    // 3-KB scratch in LDS when it stages them (PN_WG_UNIT_COAL; both access patterns are conflict-free: contiguous 16-byte writes,
+    // 16-byte reads at a stride of 48 bytes).  Loading a unit as three 16-byte pieces of its own - lanes 48 bytes apart, every
+    // instruction touching a third of each of 24 lines - streamed at 2.8 TB/s with nothing else in the kernel (timing ablations,
+    // profiles/r04_wgrad_timing_ablations.txt: 570 us for 1.61 GB, the same with or without staging and barriers, 824 us for the
+    // whole kernel), against 5.8 - 6.0 TB/s for the tiles whose loads are contiguous across the lanes.
+#ifndef PN_WG_UNIT_COAL
+#define PN_WG_UNIT_COAL 0
+#endif
+    constexpr bool COAL = PN_WG_UNIT_COAL && (X24 || Y24);
+    constexpr int SCR = COAL ? (NTH / 64) * 1536 : 0;  // unsigned shorts: 3 KB per wave
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF + SCR];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
@@ -2008,6 +2032,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
     // Segment cursor of the loads (half blocks are loaded in increasing order): the segment's pointers, widths and
     // exponents are fetched when the range crosses into it, not per half block - two dependent scalar loads in front of
     // every half block's global loads otherwise.
+    // (Do NOT force the cursor into scalar registers with v_readfirstlane: hipcc then waits s_waitcnt vmcnt(0) - for every operand
+    // load in flight - in front of every staging instead of the counted vmcnt(9) / (11) of the alternating loop; as written the
+    // segment's fields come by scalar loads and only the segment switch, which reads the two tensor maxima, drains.)
     int csg = 0, cFX = a.seg[0].FX, cFY = a.seg[0].FY, csx = 0, csy = 0;
     int64_t cbase = 0, cend = a.seg[0].nhalf;
     const TE* cX = reinterpret_cast<const TE*>(a.seg[0].X);
@@ -2058,10 +2085,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
             for (int i = 0; i < LU; ++i) {
                 const int u = unit_of(i);
                 if ((UX + UY) % NTH == 0 || u < UX + UY) {
-                    const f32x4* p = reinterpret_cast<const f32x4*>(u < UX ? xq + u * 48 : yq + (u - UX) * 48);  // (wave-uniform)
-                    ur[set][i][0] = WG_LDU(p);
-                    ur[set][i][1] = WG_LDU(p + 1);
-                    ur[set][i][2] = WG_LDU(p + 2);
+                    if constexpr (COAL) {  // the wave's 64 units as one contiguous 3-KB chunk: pieces lane, lane + 64, lane + 128
+                        const int u0 = u - lane;
+                        const f32x4* p = reinterpret_cast<const f32x4*>(u0 < UX ? xq + u0 * 48 : yq + (u0 - UX) * 48) + lane;  // (wave-uniform base)
+                        ur[set][i][0] = WG_LD(p);
+                        ur[set][i][1] = WG_LD(p + 64);
+                        ur[set][i][2] = WG_LD(p + 128);
+                    } else {
+                        const f32x4* p = reinterpret_cast<const f32x4*>(u < UX ? xq + u * 48 : yq + (u - UX) * 48);  // (wave-uniform)
+                        ur[set][i][0] = WG_LDU(p);
+                        ur[set][i][1] = WG_LDU(p + 1);
+                        ur[set][i][2] = WG_LDU(p + 2);
+                    }
                 }
             }
         }
@@ -2129,16 +2164,51 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
             if (bs) bs[f] += w * ((v[0] + v[1]) + (v[2] + v[3]));
         }
     };
+#ifndef PN_ABL_WG  // timing ablations of the weight-gradient tile (wrong results; never in the shipped build): bit 0 no matrix
+#define PN_ABL_WG 0  // products, bit 1 no staging (the loaded registers are only consumed), bit 2 no barriers
+#endif
     auto stage = [&](int buf, int set) __attribute__((always_inline)) {
         unsigned short* xs = smem + buf * BUF;
         unsigned short* ys = xs + NP * PX;
+        if constexpr (PN_ABL_WG & 2) {  // keep the loads alive, convert nothing
+            if constexpr (X24 || Y24) {
+#pragma unroll
+                for (int i = 0; i < LU; ++i) asm volatile("" ::"v"(ur[set][i][0]), "v"(ur[set][i][1]), "v"(ur[set][i][2]));
+            }
+            if constexpr (!X24) {
+#pragma unroll
+                for (int i = 0; i < LX; ++i) asm volatile("" ::"v"(xr[set][i]));
+            }
+            if constexpr (!Y24) {
+#pragma unroll
+                for (int i = 0; i < LY; ++i) asm volatile("" ::"v"(yr[set][i]));
+            }
+            return;
+        }
         if constexpr (X24 || Y24) {
 #pragma unroll
             for (int i = 0; i < LU; ++i) {
                 const int u = unit_of(i);
                 if ((UX + UY) % NTH == 0 || u < UX + UY) {
-                    if (u < UX) put_unit(xs, PX, u, ur[set][i], sx[set], bsum4[i], bw[set]);  // (wave-uniform)
-                    else put_unit(ys, PY, u - UX, ur[set][i], sy[set], nullptr, 0.f);
+                    if constexpr (COAL) {  // pieces -> this lane's unit, through the wave's scratch (LDS operations of a wave are in order)
+                        f32x4* scr = reinterpret_cast<f32x4*>(smem + 2 * BUF) + wid * 192;
+                        scr[lane] = ur[set][i][0];
+                        scr[lane + 64] = ur[set][i][1];
+                        scr[lane + 128] = ur[set][i][2];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        f32x4 un[3];
+                        un[0] = scr[3 * lane];
+                        un[1] = scr[3 * lane + 1];
+                        un[2] = scr[3 * lane + 2];
+                        __builtin_amdgcn_wave_barrier();  // (the next unit's pieces overwrite the scratch only behind these reads)
+                        if (u < UX) put_unit(xs, PX, u, un, sx[set], bsum4[i], bw[set]);  // (wave-uniform)
+                        else put_unit(ys, PY, u - UX, un, sy[set], nullptr, 0.f);
+                    } else {
+                        if (u < UX) put_unit(xs, PX, u, ur[set][i], sx[set], bsum4[i], bw[set]);  // (wave-uniform)
+                        else put_unit(ys, PY, u - UX, ur[set][i], sy[set], nullptr, 0.f);
+                    }
                 }
             }
         }
@@ -2172,21 +2242,98 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
         return *reinterpret_cast<const typename PlaneOf<NP>::type*>(plane + feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3));
     };
     auto compute = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (PN_ABL_WG & 1) return;
         const unsigned short* xs = smem + buf * BUF;
         const unsigned short* ys = xs + NP * PX;
+        // The Y fragments of tile column j + 1 are read BEFORE the products of column j, by inline asm with hand-counted waits.  As one
+        // fragment set re-used per column (round 3) every column's products waited for an LDS round trip with the matrix pipe idle -
+        // four bubbles of 150 - 200 cycles in a wave's 768 cycles of products per half block, in the phase in which its SIMD partner
+        // is staging and cannot fill them: the 256 x 256 tile ran 3300 cycles per half block against 1536 of matrix pipe, with its
+        // loads long landed (timing ablations: the loads alone stream at 5.7 TB/s, the kernel moved 3.9:
+        // profiles/r04_wgrad_timing_ablations.txt).  Written as plain C++ with two fragment sets hipcc still allocates ONE and
+        // issues each read behind the last product that uses the old value, one instruction in front of its wait.
+        // NOT on the tile with both operands in Q24: its four register sets of units leave no room for a second fragment set
+        // (12 registers spilled: 950 us per launch against 739; with three sets 744 - no gain either way: that tile's critical
+        // path is the staging of its X units, section 14 of profiles/r03_experiments.txt).  Measured on the others, same box, us
+        // per launch in the training step: fp32 tensors 596 -> 545, Y in Q24 788 -> 752 (profiles/r04_wgrad_fragment_prefetch.txt).
+        if constexpr (X24) {
+            BFrag<NP> af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) af[i].p[p] = frag(xs + p * PX, 32 * (wm * TM + i) + fr);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                BFrag<NP> bf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bf.p[p] = frag(ys + p * PY, 32 * (wn * TN + j) + fr);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split32<NP>(af[i], bf, acc[i][j]);
+            }
+            return;
+        }
+        typedef typename PlaneOf<NP>::type Frag;
+        auto lds_of = [](const unsigned short* q) { return (uint32_t)(uintptr_t)(lds_ptr_t)q; };
+        auto fidx = [&](int feature) {  // element index of this lane's fragment of `feature` in a plane (see frag)
+            if constexpr (ROT) feature = (feature & ~3) | ((feature + (feature >> 2)) & 3);
+            return feature * 16 + ((fh ^ ((feature >> 3) & 1)) << 3);
+        };
+        // 32 more features are 512 more elements whatever the lane (the row permutation and the 16-byte swap act on fr alone)
+        const uint32_t xa = lds_of(xs) + 2 * fidx(32 * (wm * TM) + fr), ya = lds_of(ys) + 2 * fidx(32 * (wn * TN) + fr);
+        // (offsets as immediates: one address register per operand instead of one per read)
+        auto rd = [](Frag& dst, uint32_t addr, auto off) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value) : "memory");
+        };
+        static_assert(2 * NP * PX + 1024 * TM < 65536 && 2 * NP * PY + 1024 * TN < 65536, "16-bit offset field of ds_read_b128");
         BFrag<NP> af[TM];
+        BFrag<NP> bf[2];
+        auto read_b = [&](auto jc, BFrag<NP>& f) {  // Y fragments of tile column j
+            constexpr int J = decltype(jc)::value;
+            static_for<NP>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                rd(f.p[P], ya, std::integral_constant<int, 1024 * J + 2 * P * PY>{});
+            });
+        };
+        // all but the newest `left` reads have returned; ties the registers the products read to the wait
+        auto settle = [&](auto left, BFrag<NP>& f) {
+            constexpr int L = decltype(left)::value;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (p == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f.p[p]) : "n"(L) : "memory");
+                else asm volatile("" : "+v"(f.p[p]));
+            }
+        };
+        read_b(std::integral_constant<int, 0>{}, bf[0]);
+        static_for<TM>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            static_for<NP>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                rd(af[I].p[P], xa, std::integral_constant<int, 1024 * I + 2 * P * PX>{});
+            });
+        });
+        if constexpr (TN > 1) {
+            read_b(std::integral_constant<int, 1>{}, bf[1]);
+            settle(std::integral_constant<int, NP>{}, bf[0]);
+        } else {
+            settle(std::integral_constant<int, 0>{}, bf[0]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) af[i].p[p] = frag(xs + p * PX, 32 * (wm * TM + i) + fr);
+            for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(af[i].p[p]));
+        static_for<TN>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            BFrag<NP> bf;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) bf.p[p] = frag(ys + p * PY, 32 * (wn * TN + j) + fr);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split32<NP>(af[i], bf, acc[i][j]);
-        }
+            for (int i = 0; i < TM; ++i) acc[i][J] = mfma_split32<NP>(af[i], bf[J & 1], acc[i][J]);
+            if constexpr (J + 2 < TN) {  // column J + 2 into the set column J's products have just been issued from
+                __builtin_amdgcn_sched_barrier(0);
+                read_b(std::integral_constant<int, J + 2>{}, bf[J & 1]);
+            }
+            if constexpr (J + 1 < TN) {
+                if constexpr (J + 2 < TN) settle(std::integral_constant<int, NP>{}, bf[(J + 1) & 1]);
+                else settle(std::integral_constant<int, 0>{}, bf[(J + 1) & 1]);
+            }
+        });
     };
 #ifdef PN_TRACE_WG  // debug build only: phase times of workgroup 0 (every wave), summed over its half blocks
     unsigned long long tw[4] = {0, 0, 0, 0};
@@ -2238,11 +2385,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
                 constexpr int K = decltype(kc)::value;
                 if (!decltype(guard)::value || k0 + K < n) {  // (uniform)
                     WGT(3, compute(K % 2));
-                    if (t) WGT(1, __syncthreads());
+                    if (t && !(PN_ABL_WG & 4)) WGT(1, __syncthreads());
                     const int64_t hb = k0 + K + 1 + t;
                     if (hb < n) WGT(0, stage((K + 1 + t) & 1, (K + 1) % NSET));
                     WGT(2, load(clampd(hb + NSET), (K + 1) % NSET));
-                    if (!t) WGT(1, __syncthreads());
+                    if (!t && !(PN_ABL_WG & 4)) WGT(1, __syncthreads());
                 }
             };
             int64_t k0 = 0;

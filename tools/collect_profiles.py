@@ -1,4 +1,4 @@
-"""Copy the outputs of tools/final_measure.sh (gpurun_out/final, gpurun_out/pmcx_sq) into profiles/ under round-3 names.
+"""Copy the outputs of tools/final_measure.sh (gpurun_out/final, gpurun_out/pmcx_sq) into profiles/ under the round's names.
 usage: python tools/collect_profiles.py <tag>      e.g. r03_v1"""
 import collections, csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +7,8 @@ F, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
 pairs = [("bench_default.json", f"{tag}_bench_default.json"), ("bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json"),
          ("kt/kt_kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("bench_b512.json", f"{tag}_b512_graph_bench.json"),
          ("bench_fused.json", f"{tag}_fused_bf16x3_bench.json"), ("bench_fused_bf16.json", f"{tag}_fused_bf16_bench.json"),
-         ("bench_layerwise.json", f"{tag}_layerwise_bench.json"), ("pmc_summary.json", "r03_pmc_summary.json")]
+         ("bench_layerwise.json", f"{tag}_layerwise_bench.json"), ("bench_fused_f16x2_t32.json", f"{tag}_fused_f16x2_t32_bench.json"),
+         ("pmc_summary.json", "r04_pmc_summary.json"), ("pmc_summary_cfg2.json", "r04_pmc_summary_cfg2_bf16.json")]
 for src, dst in pairs:
     s = os.path.join(F, src)
     if os.path.exists(s) and os.path.getsize(s) > 0:
