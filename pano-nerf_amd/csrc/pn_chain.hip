@@ -1116,15 +1116,19 @@ __device__ __forceinline__ Tile tile_of(int64_t st, int wid, int lane, int64_t M
     return t;
 }
 // T store of an F-feature vector of this wave's tile into the tensor at `slot`: fp32 T layout, or Q24 (`q`: wave-uniform)
+// (The lane's part of the address goes through `opaque`: as a plain expression hipcc hoists "tensor base + lane offset" for every slot
+// and both formats out of the tile loop as 64-bit pointers - with the run-time format flag of ABI 2 four of them no longer fitted the
+// 256 registers, were SPILLED, and every epilogue reloaded one from scratch in front of its stores: a vector-memory load, i.e. an
+// s_waitcnt vmcnt(0) that also waits for the weight ring's DMA pieces in flight and for the previous layer's stores.)
 template <int NP, int NT>
 __device__ __forceinline__ void store_vec(typename TEl<NP>::type* slot, const Tile& T, int F, bool q, const accv (&acc)[NT]) {
     if constexpr (kQ24<NP>) {
         if (q) {
-            store_q24<NT>(reinterpret_cast<unsigned char*>(slot) + T.blk * (int64_t)(F * TILE * 3) + q24_lane(T.c, T.g), acc);
+            store_q24<NT>(reinterpret_cast<unsigned char*>(slot) + T.blk * (int64_t)(F * TILE * 3) + opaque(q24_lane(T.c, T.g)), acc);
             return;
         }
     }
-    store_t<NT>(slot + T.blk * (int64_t)(F * TILE) + T.lo, acc);
+    store_t<NT>(slot + T.blk * (int64_t)(F * TILE) + opaque(T.lo), acc);
 }
 
 // integrated positional encoding (MODE 0), or its tangent along v (MODE 1), of this lane's 96 / NG features -> T-layout
@@ -2256,7 +2260,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_chain_wgrad(WgMulti multi) {
         // (12 registers spilled: 950 us per launch against 739; with three sets 744 - no gain either way: that tile's critical
         // path is the staging of its X units, section 14 of profiles/r03_experiments.txt).  Measured on the others, same box, us
         // per launch in the training step: fp32 tensors 596 -> 545, Y in Q24 788 -> 752 (profiles/r04_wgrad_fragment_prefetch.txt).
-        if constexpr (X24) {
+#ifndef PN_WG_X24_PREFETCH  // (experiment switch: the prefetching form on the Q24 tile too; needs PN_WG_Q24_NSET=3 to fit)
+#define PN_WG_X24_PREFETCH 0
+#endif
+        if constexpr (X24 && !PN_WG_X24_PREFETCH) {
             BFrag<NP> af[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
