@@ -374,10 +374,13 @@ def hdr_to_ldr(color, gamma=2.2, quantize=False):
 # --------------------------------------------------------------------- full forwards
 def pano_forward(p, rays, env_rays, *, num_samples, white_bkgd=False, enable_surf=True,
                  use_ort_loss=True, noise=None, num_env_samples=10, resample_padding=0.01,
-                 rgb_padding=0.0, density_bias=-1.0, normals_mode="fast", disparity=False):
+                 rgb_padding=0.0, density_bias=-1.0, normals_mode="fast", disparity=False, disable_integration=False):
     """PanoMipNeRF.forward, models/pano_mip_nerf.py:197-363.
-    ``noise`` = None (deterministic) or dict(t_rand [B,S], u_rand [B,S], env_rand [1,Ne+1])."""
+    ``noise`` = None (deterministic) or dict(t_rand [B,S], u_rand [B,S], env_rand [1,Ne+1]).
+    ``disable_integration``: every encoding sees a zero covariance (models/pano_mip_nerf.py:241-243, inside compute_graph:
+    both levels, the density-gradient normals and the env-light evaluation)."""
     kw = dict(rgb_padding=rgb_padding, density_bias=density_bias)
+    zc = (lambda c: torch.zeros_like(c)) if disable_integration else (lambda c: c)
     env = Rays(*[x.float() for x in env_rays])
     ret = []
     t, w = None, None
@@ -388,6 +391,7 @@ def pano_forward(p, rays, env_rays, *, num_samples, white_bkgd=False, enable_sur
         else:
             t, (mean, cov) = resample_along_rays(rays.origins, rays.directions, rays.radii, t, w.detach().clone(),
                                                  resample_padding, None if noise is None else noise["u_rand"])
+        cov = zc(cov)
         rgb, sigma, albedos = radiance_field(p, mean, cov, rays.viewdirs, **kw)
         comp, dist, acc, w = volumetric_rendering(rgb, sigma, t, rays.directions, white_bkgd)
         normal = surf = albedo = diffuse = ort = shading = None
@@ -405,7 +409,7 @@ def pano_forward(p, rays, env_rays, *, num_samples, white_bkgd=False, enable_sur
                 lt, (lm, lc), ldirs = sample_each_points(
                     x_surf, env.directions, num_env_samples, env.near, env.far, env.radii,
                     None if noise is None else noise["env_rand"])
-                lrgb, lsig, _ = radiance_field(p, lm, lc, ldirs, **kw)
+                lrgb, lsig, _ = radiance_field(p, lm, zc(lc), ldirs, **kw)
                 env_rgb = volumetric_rendering(lrgb, lsig, lt, ldirs, False)[0].view(normal.shape[0], -1, 3)
                 surf, diffuse, shading = surface_rendering(env_rgb, albedo, normal, ldirs.view(env_rgb.shape),
                                                            env.lossmult)
@@ -414,9 +418,11 @@ def pano_forward(p, rays, env_rays, *, num_samples, white_bkgd=False, enable_sur
 
 
 def mip_forward(p, rays, *, num_samples, white_bkgd=False, use_ort_loss=False, noise=None,
-                resample_padding=0.01, rgb_padding=0.0, density_bias=-1.0, normals_mode="fast", disparity=False):
-    """MipNeRF.forward, models/mip_nerf.py:170-283."""
+                resample_padding=0.01, rgb_padding=0.0, density_bias=-1.0, normals_mode="fast", disparity=False,
+                disable_integration=False):
+    """MipNeRF.forward, models/mip_nerf.py:170-283 (disable_integration: :215-216)."""
     kw = dict(rgb_padding=rgb_padding, density_bias=density_bias)
+    zc = (lambda c: torch.zeros_like(c)) if disable_integration else (lambda c: c)
     ret = []
     t, w = None, None
     for level in range(2):
@@ -426,6 +432,7 @@ def mip_forward(p, rays, *, num_samples, white_bkgd=False, use_ort_loss=False, n
         else:
             t, (mean, cov) = resample_along_rays(rays.origins, rays.directions, rays.radii, t, w.detach().clone(),
                                                  resample_padding, None if noise is None else noise["u_rand"])
+        cov = zc(cov)
         rgb, sigma, _ = radiance_field(p, mean, cov, rays.viewdirs, **kw)
         comp, dist, acc, w = volumetric_rendering(rgb, sigma, t, rays.directions, white_bkgd)
         if level == 1 and use_ort_loss:

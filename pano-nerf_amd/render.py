@@ -239,6 +239,8 @@ class _RenderFn(torch.autograd.Function):
             e0.t = e(B, S)
             _lib.call("pn_sample_coarse", B, N, int(cfg.disparity), o.data_ptr(), d.data_ptr(), radii.data_ptr(), near.data_ptr(),
                       far.data_ptr(), _lib.ptr(t_rand), e0.t.data_ptr(), e0.mean.data_ptr(), e0.cov.data_ptr(), st)
+            if cfg.disable_integration:  # models/pano_mip_nerf.py:241-243: every encoding of compute_graph sees a zero covariance
+                e0.cov.zero_()
             _mlp_forward(e0, params, wpack, st)
             comp0, dist0, _, w0 = _composite_forward(e0, B, N, cfg, cfg.white_bkgd, d, B, st)
             if not keep:
@@ -249,6 +251,8 @@ class _RenderFn(torch.autograd.Function):
             _lib.call("pn_resample", B, N, e0.t.data_ptr(), w0.data_ptr(), cfg.resample_padding, _lib.ptr(u_rand),
                       o.data_ptr(), d.data_ptr(), radii.data_ptr(), e1.t.data_ptr(), e1.mean.data_ptr(),
                       e1.cov.data_ptr(), st)
+            if cfg.disable_integration:
+                e1.cov.zero_()
             _mlp_forward(e1, params, wpack, st)
             comp1, dist1, _, w1 = _composite_forward(e1, B, N, cfg, cfg.white_bkgd, d, B, st)
             normal = ort = albedo = surface = diffuse = shading = None
@@ -286,6 +290,8 @@ class _RenderFn(torch.autograd.Function):
                 _lib.call("pn_sample_env", B, D, Ne, o.data_ptr(), d.data_ptr(), dist1.data_ptr(), env_d.data_ptr(),
                           env_rad.data_ptr(), env_near.data_ptr(), env_far.data_ptr(), _lib.ptr(env_rand),
                           ee.t.data_ptr(), ee.mean.data_ptr(), ee.cov.data_ptr(), st)
+                if cfg.disable_integration:
+                    ee.cov.zero_()
                 _mlp_forward(ee, params, wpack, st)
                 env_rgb, _, _, _ = _composite_forward(ee, B * D, Ne, cfg, False, env_d, D, st)
                 diffuse, shading = e(B, 3), e(B, 3)
@@ -483,8 +489,9 @@ class _RenderBase(torch.nn.Module):
         unsupported = []
         if num_levels != 2: unsupported.append("num_levels != 2")
         if not stop_resample_grad: unsupported.append("stop_resample_grad=False")
+        # (upstream itself cannot run use_viewdirs=False: its MLP then feeds the 256-wide trunk output to the 128-input colour layer,
+        # models/pano_mip_nerf.py:99-113 - "mat1 and mat2 shapes cannot be multiplied (32x256 and 128x3)")
         if not use_viewdirs: unsupported.append("use_viewdirs=False")
-        if disable_integration: unsupported.append("disable_integration=True")
         if density_noise and density_noise > 0: unsupported.append("density_noise > 0")
         if (min_deg_point, max_deg_point, deg_view) != (0, 16, 4): unsupported.append("encoding degrees != (0,16,4)")
         if not append_identity: unsupported.append("append_identity=False")
@@ -495,6 +502,7 @@ class _RenderBase(torch.nn.Module):
         self.num_samples, self.num_levels = int(num_samples), int(num_levels)
         self.resample_padding = float(resample_padding)
         self.disparity = bool(disparity)  # coarse samples linear in inverse depth (models/mip.py:134-136)
+        self.disable_integration = bool(disable_integration)  # PE instead of IPE: zero covariance in every encoding (:241-243)
         self.density_bias, self.rgb_padding = float(density_bias), float(rgb_padding)
         self.num_env_samples = int(num_env_samples)
         self.mlp = RadianceMLP(mlp_net_depth, mlp_net_width, mlp_net_depth_condition, mlp_net_width_condition,
@@ -576,6 +584,7 @@ class _RenderBase(torch.nn.Module):
         t_rand, u_rand, env_rand = self._noise(randomized, o.shape[0], dev, surf)
         cfg = _Cfg(num_samples=self.num_samples, nc=self._NC, density_bias=self.density_bias,
                    rgb_padding=self.rgb_padding, resample_padding=self.resample_padding, disparity=self.disparity,
+                   disable_integration=self.disable_integration,
                    white_bkgd=bool(white_bkgd), surf=bool(surf), use_ort=bool(use_ort), normals=bool(normals),
                    num_env_samples=self.num_env_samples, overlap=self.overlap_weight_grads, planes=_planes_of(self.mlp_mode),
                    tfmt=_tfmt_of(self.mlp_mode), chain_wgs=int(self.overlap_chain_wgs), wgrad_wgs=int(self.overlap_wgrad_wgs),

@@ -253,3 +253,40 @@ def test_oracle_disparity_sampling_and_forward(golden):
                 assert rel_err(v, g[f"pano/l{lvl}/{n}"]) < (5e-3 if n in ("normal", "surface_rgb", "diffuse", "shading", "ort_loss") else 1e-5), (lvl, n)
     for lvl in (0, 1):
         assert rel_err(mouts[lvl][0], g[f"mip/l{lvl}/comp_rgb"]) < 1e-5 and rel_err(mouts[lvl][1], g[f"mip/l{lvl}/distance"]) < 1e-5
+
+
+def test_oracle_disable_integration(golden):
+    """`disable_integration=True` (compute_graph zeroes the covariance: models/pano_mip_nerf.py:241-243, models/mip_nerf.py:213-214):
+    the oracle against the reference's val-mode tuples of both models, and its train-mode loss and full gradient
+    (tests/golden/make_disint_golden.py)."""
+    g = golden("disable_integration_B16_N32")
+    rays = orc.Rays(*[torch.from_numpy(g["ray_" + k]) for k in orc.Rays._fields])
+    N = g["t_rand"].shape[1] - 1
+    env = orc.generate_lit_rays(10, float(orc.synthetic_scene(8, 16, 3, seed=4)[2]))
+    with torch.no_grad():
+        outs = orc.pano_forward(orc.init_params(4, 5), rays, env, num_samples=N, disable_integration=True)
+        mouts = orc.mip_forward(orc.init_params(4, 1), rays, num_samples=N, use_ort_loss=True, disable_integration=True)
+        plain = orc.pano_forward(orc.init_params(4, 5), rays, env, num_samples=N)
+    names = ("comp_rgb", "distance", "ort_loss", "normal", "albedo", "roughness", "surface_rgb", "diffuse", "shading")
+    for lvl, tup in enumerate(outs):
+        for n, v in zip(names, tup):
+            if v is not None:
+                assert rel_err(v, g[f"pano/l{lvl}/{n}"]) < (5e-3 if n in ("normal", "surface_rgb", "diffuse", "shading", "ort_loss") else 1e-5), (lvl, n)
+    assert rel_err(plain[1][0], g["pano/l1/comp_rgb"]) > 1e-3  # (the flag changes the render: the fixture is not the default's)
+    for lvl in (0, 1):
+        assert rel_err(mouts[lvl][0], g[f"mip/l{lvl}/comp_rgb"]) < 1e-5 and rel_err(mouts[lvl][1], g[f"mip/l{lvl}/distance"]) < 1e-5
+    assert rel_err(mouts[1][3], g["mip/l1/normal"]) < 5e-3
+    p = {k: v.clone().requires_grad_(True) for k, v in orc.init_params(4, 5).items()}
+    noise = dict(t_rand=torch.from_numpy(g["t_rand"]), u_rand=torch.from_numpy(g["u_rand"]), env_rand=torch.from_numpy(g["env_rand"]))
+    touts = orc.pano_forward(p, rays, env, num_samples=N, noise=noise, disable_integration=True)
+    loss = orc.pano_loss(touts, rays.lossmult, torch.from_numpy(g["rgbs"]))
+    assert abs(float(loss) - float(g["train/loss"])) < 1e-5 * abs(float(g["train/loss"]))
+    grads = torch.autograd.grad(loss, list(p.values()))
+    for (k, _), gr in zip(p.items(), grads):
+        r = g["train/grad/" + k]
+        scale = max(float(np.abs(r).max()), 1e-30)
+        err = np.abs(gr.numpy() - r) / scale
+        if k.startswith(("extra_layer", "view_layers", "color_layer")):
+            assert float(err.max()) <= 1e-4, (k, float(err.max()))
+        else:
+            assert float(np.median(err)) <= 1e-4 and float(np.mean(err <= 1e-3)) >= 0.99, (k, float(np.median(err)))
